@@ -1,0 +1,295 @@
+// m4_parse.h -- the serial part of matchfinder.M4 (m4.go:109-283) as a
+// resumable state machine over a *precomputed* chain array.
+//
+// The reference interleaves hash-table insertion (m4.go:140-147, pure function
+// of the bytes) with the parse.  Here kernel K1 (k1_chain.h) has already
+// produced chain[i] = i - (latest earlier inserted position with the same
+// hash) for every inserted position, so the parse
+//   * never touches a hash table, and
+//   * JUMPS over the positions m4.go:149-151 would `continue` past (inside a
+//     pending match only position End+2-HashLen is searched),
+// which is what makes it cheap enough to run one state machine per GPU lane.
+//
+// The state between two loop iterations is (i, m0, m1, next_emit, prev_dist):
+// matches[2] of the reference is always empty at the loop top.  The machine
+// can be stopped at any position and resumed, which the speculative
+// sub-block parse (K3) relies on.
+//
+// Compiles for the device (hipcc) and, for host-side unit tests of the
+// algorithm only, for the host.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define M4G_HD __host__ __device__ __forceinline__
+#else
+#define M4G_HD inline
+#endif
+
+namespace m4g {
+
+struct ParseParams {
+  int32_t max_distance;
+  int32_t min_length;
+  int32_t hash_len;
+  int32_t chain_length;
+  int32_t distance_bit_cost;
+};
+
+// emitter.go:5-16; end == 0 <=> the reference's zero-valued absoluteMatch
+// (a real match always has End >= 5, a clipped one End >= 1).
+struct AbsMatch {
+  int32_t start, end, match;
+};
+
+// Internal 16-byte match record: m4g_match + where its literals begin.
+struct Rec {
+  uint32_t unmatched, length, distance, lit_start;
+};
+
+struct ParseState {
+  int32_t i;          // next loop position
+  AbsMatch m0, m1;    // pending matches, newest first (m4.go:111)
+  int32_t next_emit;  // matchEmitter.NextEmit (emitter.go:24)
+  uint32_t prev_dist; // e.Dst[len-1].Distance, valid iff have_prev
+  uint32_t have_prev; // len(e.Dst) > 0
+  uint32_t error;     // 1: repeat distance reaches before buffer start
+};
+
+M4G_HD uint32_t ld32(const uint8_t *p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+M4G_HD uint64_t ld64(const uint8_t *p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+M4G_HD int32_t bitlen32(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
+
+// m4.go:59-61 (64-bit: lengths reach 2^25 in streaming mode)
+M4G_HD int64_t score(const AbsMatch &m, int32_t cost) {
+  return (int64_t)(m.end - m.start) * 256 -
+         (int64_t)bitlen32((uint32_t)(m.start - m.match)) * cost;
+}
+
+// m4.go:293-324: first index >= j where src[i+k] != src[j+k], or len.
+M4G_HD int32_t extend_fwd(const uint8_t *src, int32_t len, int32_t i, int32_t j) {
+  while (j + 8 < len) {
+    uint64_t a = ld64(src + i), b = ld64(src + j);
+    if (a != b) return j + (int32_t)(__builtin_ctzll(a ^ b) >> 3);
+    i += 8;
+    j += 8;
+  }
+  while (j < len && src[i] == src[j]) {
+    i++;
+    j++;
+  }
+  return j;
+}
+
+// m4.go:328-339
+M4G_HD AbsMatch extend2(const uint8_t *src, int32_t len, int32_t start,
+                        int32_t cand, int32_t lo) {
+  AbsMatch m;
+  m.end = extend_fwd(src, len, cand + 4, start + 4);
+  while (start > lo && cand > 0 && src[start - 1] == src[cand - 1]) {
+    start--;
+    cand--;
+  }
+  m.start = start;
+  m.match = cand;
+  return m;
+}
+
+// matchEmitter.emit (emitter.go:27-34) into a caller-provided sink.
+template <class Sink>
+M4G_HD void emit(ParseState &S, const AbsMatch &m, Sink &sink) {
+  Rec r;
+  r.unmatched = (uint32_t)(m.start - S.next_emit);
+  r.length = (uint32_t)(m.end - m.start);
+  r.distance = (uint32_t)(m.start - m.match);
+  r.lit_start = (uint32_t)S.next_emit;
+  sink.push(r);
+  S.next_emit = m.end;
+  S.prev_dist = r.distance;
+  S.have_prev = 1;
+}
+
+// m4.go:113-126 / 262-273: emit the (clipped) older match, then the newest.
+template <class Sink>
+M4G_HD void flush(ParseState &S, const ParseParams &P, Sink &sink) {
+  if (S.m1.end != 0) {
+    if (S.m1.end > S.m0.start) S.m1.end = S.m0.start;
+    if (S.m1.end - S.m1.start >= P.min_length && score(S.m1, P.distance_bit_cost) > 0)
+      emit(S, S.m1, sink);
+  }
+  emit(S, S.m0, sink);
+  S.m0 = AbsMatch{0, 0, 0};
+  S.m1 = AbsMatch{0, 0, 0};
+}
+
+M4G_HD void state_init(ParseState &S, int32_t start, uint32_t seed_prev_distance) {
+  S.i = start;
+  S.m0 = AbsMatch{0, 0, 0};
+  S.m1 = AbsMatch{0, 0, 0};
+  S.next_emit = start;
+  S.prev_dist = seed_prev_distance;
+  S.have_prev = seed_prev_distance != 0;
+  S.error = 0;
+}
+
+// Runs loop iterations of m4.go:112-260 while S.i < stop (stop <= len-7).
+// `src`/`chain` are indexed by buffer position; `len` is the buffer length
+// (forward extension may read up to len, never past it).
+template <class Sink>
+M4G_HD void parse_range(const uint8_t *__restrict__ src, int32_t len,
+                        const uint32_t *__restrict__ chain, const ParseParams &P,
+                        ParseState &S, int32_t stop, Sink &sink) {
+  int32_t i = S.i;
+  while (i < stop) {
+    // A. m4.go:113-126
+    if (S.m0.end != 0 && i >= S.m0.end) flush(S, P, sink);
+
+    // B. m4.go:128-138 repeat match one byte after the current position
+    if (S.m0.end == 0 && S.have_prev) {
+      int32_t p = i + 1;
+      int32_t c = p - (int32_t)S.prev_dist;
+      if (c < 0) {
+        S.error = 1; // the Go code would panic on the slice bounds
+      } else if (ld32(src + p) == ld32(src + c)) {
+        AbsMatch m = extend2(src, len, p, c, S.next_emit + 1);
+        if (m.end - m.start >= P.min_length) S.m0 = m;
+      }
+    }
+
+    // D. m4.go:149-151; positions in between only insert hashes (done by K1)
+    if (S.m0.end != 0 && i < S.m0.end) {
+      int32_t probe = S.m0.end + 2 - P.hash_len;
+      if (i != probe) {
+        i = (probe > i && probe < S.m0.end) ? probe : S.m0.end;
+        continue;
+      }
+    }
+
+    // C+D. candidate = table[h] before insertion == i - chain[i]
+    uint32_t d = chain[i];
+    if (d == 0 || d > (uint32_t)P.max_distance) {
+      i++;
+      continue;
+    }
+    int32_t cand = i - (int32_t)d;
+
+    // E. m4.go:156-181
+    AbsMatch cur{0, 0, 0};
+    int64_t cur_score = 0;
+    const uint32_t w = ld32(src + i);
+    if (ld32(src + cand) == w) {
+      AbsMatch m = extend2(src, len, i, cand, S.next_emit);
+      if (m.end - m.start > P.min_length) {
+        int64_t sc = score(m, P.distance_bit_cost);
+        if (sc > 0) {
+          cur = m;
+          cur_score = sc;
+        }
+      }
+    }
+    for (int32_t j = 0; j < P.chain_length; j++) {
+      uint32_t dd = chain[cand];
+      if (dd == 0) break;
+      // Go: candidate -= int(delta) in 64-bit; dd > cand means candidate <= 0
+      if (dd >= (uint32_t)cand) break;
+      cand -= (int32_t)dd;
+      if (i - cand > P.max_distance) break;
+      if (ld32(src + cand) == w) {
+        AbsMatch m = extend2(src, len, i, cand, S.next_emit);
+        if (m.end - m.start > P.min_length) {
+          int64_t sc = score(m, P.distance_bit_cost);
+          if (sc > cur_score) {
+            cur = m;
+            cur_score = sc;
+          }
+        }
+      }
+    }
+    // m4.go:183-185
+    if (cur.end - cur.start < P.min_length) {
+      i++;
+      continue;
+    }
+
+    // F. m4.go:187-199
+    int64_t penalty = 0;
+    if (S.m0.end != 0) {
+      penalty = 275;
+      if (cur.start <= S.m1.end) penalty = 0;
+    }
+    if (cur_score <= score(S.m0, P.distance_bit_cost) + penalty) {
+      i++;
+      continue;
+    }
+
+    // m4.go:201-209
+    AbsMatch m2 = S.m1;
+    S.m1 = S.m0;
+    S.m0 = cur;
+    if (m2.end != 0) {
+      // G. m4.go:211-259
+      if (S.m0.start < m2.end) {
+        S.m1 = m2;
+      } else if (S.m0.start < m2.end + P.min_length) {
+        emit(S, m2, sink);
+        S.m1 = AbsMatch{0, 0, 0};
+      } else {
+        if (m2.end > S.m1.start) {
+          m2.end = S.m1.start;
+          int32_t mlen = m2.end - m2.start;
+          if (P.chain_length > 0 && mlen >= P.min_length) {
+            // m4.go:236-252: look for a closer source for the trimmed match
+            int32_t pos = m2.start;
+            for (;;) {
+              uint32_t dd = chain[pos];
+              if (dd == 0) break;
+              if ((int64_t)pos - (int64_t)dd <= (int64_t)m2.match) break;
+              pos -= (int32_t)dd;
+              int32_t k = 0;
+              while (k < mlen && src[m2.start + k] == src[pos + k]) k++;
+              if (k == mlen) {
+                m2.match = pos;
+                break;
+              }
+            }
+          }
+        }
+        if (m2.end - m2.start >= P.min_length && score(m2, P.distance_bit_cost) > 0)
+          emit(S, m2, sink);
+      }
+    }
+    i++;
+  }
+  S.i = i;
+}
+
+// m4.go:262-281: after the loop, emit what is pending plus the trailing
+// literal run.
+template <class Sink>
+M4G_HD void parse_finish(int32_t len, const ParseParams &P, ParseState &S, Sink &sink) {
+  if (S.m1.end != 0) {
+    if (S.m1.end > S.m0.start) S.m1.end = S.m0.start;
+    if (S.m1.end - S.m1.start >= P.min_length && score(S.m1, P.distance_bit_cost) > 0)
+      emit(S, S.m1, sink);
+  }
+  if (S.m0.end != 0) emit(S, S.m0, sink);
+  if (S.next_emit < len) {
+    Rec r;
+    r.unmatched = (uint32_t)(len - S.next_emit);
+    r.length = 0;
+    r.distance = 0;
+    r.lit_start = (uint32_t)S.next_emit;
+    sink.push(r);
+  }
+}
+
+} // namespace m4g

@@ -1,0 +1,687 @@
+// m4g.hip -- host side of libm4g.so: the C-ABI of include/m4g.h over the
+// gfx950 kernels in kernels.h.  No CPU compute path exists in this library.
+#include "../../include/m4g.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace m4g;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return fail(M4G_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// m4.go:64-75 defaults
+struct Params {
+  int32_t max_distance, min_length, hash_len, table_bits, chain_length, distance_bit_cost;
+};
+
+int resolve_params(const m4g_params *in, Params *p) {
+  if (!in) return fail(M4G_ERR_BAD_PARAM, "params is NULL");
+  p->max_distance = in->max_distance ? in->max_distance : 65535;
+  p->min_length = in->min_length ? in->min_length : 4;
+  p->hash_len = in->hash_len ? in->hash_len : 6;
+  p->table_bits = in->table_bits ? in->table_bits : 17;
+  p->chain_length = in->chain_length;
+  p->distance_bit_cost = in->distance_bit_cost;
+  if (p->max_distance < 1 || p->min_length < 1 || p->hash_len < 1 || p->hash_len > 8 ||
+      p->table_bits < 1 || p->table_bits > 24 || p->chain_length < 0 || p->distance_bit_cost < 0)
+    return fail(M4G_ERR_BAD_PARAM, "parameter out of range");
+  return M4G_OK;
+}
+
+ParseParams parse_params(const Params &p) {
+  ParseParams P;
+  P.max_distance = p.max_distance;
+  P.min_length = p.min_length;
+  P.hash_len = p.hash_len;
+  P.chain_length = p.chain_length;
+  P.distance_bit_cost = p.distance_bit_cost;
+  return P;
+}
+
+constexpr int kMaxPartBits = 15; // 2^15 * 4 B = 128 KiB of LDS
+
+int part_bits_of(const Params &p) { return std::min(p.table_bits, kMaxPartBits); }
+size_t k1_lds_bytes(int part_bits) {
+  return ((size_t)1 << part_bits) * 4 + (size_t)K1_THREADS * 8 + 16;
+}
+
+int check_device(int device) {
+  if (device < 0)
+    return fail(M4G_ERR_NO_DEVICE,
+                "device < 0: libm4g has no CPU backend (the CPU oracle is test infrastructure)");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(M4G_ERR_NO_DEVICE, "no HIP device available");
+  if (device >= n) return fail(M4G_ERR_NO_DEVICE, "device index out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return fail(M4G_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(M4G_ERR_NO_DEVICE,
+                std::string("device is ") + prop.gcnArchName + ", libm4g is built for gfx950 only");
+  return M4G_OK;
+}
+
+int k1_prepare() {
+  // > 64 KiB of dynamic LDS needs the attribute once per device.
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1_chain_build),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)k1_lds_bytes(kMaxPartBits)));
+  return M4G_OK;
+}
+
+// Launches K1 + K3 for `njobs` jobs whose descriptors are already in d_jobs.
+int launch_find(const Params &p, const uint8_t *d_src, uint32_t *d_chain, const Job *d_jobs,
+                uint32_t *d_table_io, int njobs, Rec *d_slots, uint32_t *d_counts,
+                uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
+  const int pb = part_bits_of(p);
+  const int nparts = 1 << (p.table_bits - pb);
+  const int groups = (njobs + 7) / 8;
+  dim3 g1((unsigned)(groups * 8 * nparts));
+  hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, d_chain,
+                     d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb);
+  HIP_TRY(hipGetLastError());
+  if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st));
+  hipLaunchKernelGGL(k3_parse_serial, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain,
+                     d_jobs, d_slots, d_counts, d_errors, njobs, parse_params(p));
+  HIP_TRY(hipGetLastError());
+  return M4G_OK;
+}
+
+} // namespace
+
+// ===========================================================================
+// misc
+// ===========================================================================
+extern "C" const char *m4g_strerror(int code) {
+  switch (code) {
+  case M4G_OK: return "ok";
+  case M4G_ERR_NO_DEVICE: return "no usable gfx950 device (libm4g has no CPU backend)";
+  case M4G_ERR_BAD_PARAM: return "bad parameter";
+  case M4G_ERR_HIP: return "HIP runtime error";
+  case M4G_ERR_TOO_LARGE: return "input too large";
+  case M4G_ERR_NO_MEMORY: return "out of memory";
+  case M4G_ERR_REPEAT_RANGE: return "seeded repeat distance reaches before the history start";
+  default: return code < 0 ? "output buffer too small (-(needed) returned)" : "ok";
+  }
+}
+extern "C" const char *m4g_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int m4g_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; d++) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess &&
+        std::strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+      ok++;
+  }
+  return ok;
+}
+
+extern "C" void *m4g_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+extern "C" void m4g_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+// ===========================================================================
+// batch plan
+// ===========================================================================
+struct m4g_batch {
+  int device = 0;
+  Params p{};
+  size_t max_chunks = 0, max_chunk_bytes = 0, slot_cap = 0;
+  uint32_t *d_chain = nullptr;
+  Rec *d_slots = nullptr;
+  uint32_t *d_pf = nullptr;
+  uint32_t *d_counts = nullptr;
+  uint32_t *d_errors = nullptr;
+  Job *d_jobs = nullptr;
+  std::vector<uint64_t> last_off; // chunk_off of the jobs currently in d_jobs
+  bool timing = false, ran = false;
+  hipEvent_t ev[5] = {};
+  hipStream_t last_stream = nullptr;
+};
+
+extern "C" void m4g_batch_destroy(m4g_batch *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  (void)hipFree(b->d_chain);
+  (void)hipFree(b->d_slots);
+  (void)hipFree(b->d_pf);
+  (void)hipFree(b->d_counts);
+  (void)hipFree(b->d_errors);
+  (void)hipFree(b->d_jobs);
+  for (auto &e : b->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete b;
+}
+
+extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max_chunks,
+                                size_t max_chunk_bytes, m4g_batch **out) {
+  if (!out) return fail(M4G_ERR_BAD_PARAM, "out is NULL");
+  *out = nullptr;
+  Params p;
+  int rc = resolve_params(params, &p);
+  if (rc) return rc;
+  if ((rc = check_device(device))) return rc;
+  if (max_chunks == 0 || max_chunks > (1u << 24))
+    return fail(M4G_ERR_BAD_PARAM, "max_chunks out of range");
+  if (max_chunk_bytes == 0 || max_chunk_bytes > ((size_t)1 << 24))
+    return fail(M4G_ERR_TOO_LARGE, "max_chunk_bytes above 2^24 (largest brotli meta-block)");
+  HIP_TRY(hipSetDevice(device));
+  if ((rc = k1_prepare())) return rc;
+
+  m4g_batch *b = new m4g_batch();
+  b->device = device;
+  b->p = p;
+  b->max_chunks = max_chunks;
+  b->max_chunk_bytes = max_chunk_bytes;
+  b->slot_cap = max_chunk_bytes / (size_t)p.min_length + 2;
+  const size_t nbytes = max_chunks * max_chunk_bytes;
+  const size_t nrec = max_chunks * b->slot_cap;
+  hipError_t e;
+  if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 64)) != hipSuccess ||
+      (e = hipMalloc(&b->d_slots, nrec * sizeof(Rec))) != hipSuccess ||
+      (e = hipMalloc(&b->d_pf, nrec * 4)) != hipSuccess ||
+      (e = hipMalloc(&b->d_counts, max_chunks * 4)) != hipSuccess ||
+      (e = hipMalloc(&b->d_errors, 64)) != hipSuccess ||
+      (e = hipMalloc(&b->d_jobs, max_chunks * sizeof(Job))) != hipSuccess) {
+    std::string msg = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
+    m4g_batch_destroy(b);
+    return fail(M4G_ERR_NO_MEMORY, msg);
+  }
+  for (auto &ev : b->ev) {
+    if (hipEventCreate(&ev) != hipSuccess) {
+      m4g_batch_destroy(b);
+      return fail(M4G_ERR_HIP, "hipEventCreate failed");
+    }
+  }
+  *out = b;
+  return M4G_OK;
+}
+
+extern "C" void m4g_batch_set_timing(m4g_batch *b, int enabled) {
+  if (b) b->timing = enabled != 0;
+}
+
+extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const uint64_t *chunk_off,
+                                    size_t nchunks, m4g_match *d_out, uint64_t *d_out_off,
+                                    size_t out_cap, m4g_histo *d_histos, void *hip_stream) {
+  if (!b || !chunk_off || !d_out_off || (!d_out && out_cap))
+    return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (nchunks > b->max_chunks) return fail(M4G_ERR_TOO_LARGE, "nchunks above the plan's max_chunks");
+  if (nchunks && !d_src) return fail(M4G_ERR_BAD_PARAM, "d_src is NULL");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int njobs = (int)nchunks;
+  b->ran = false;
+
+  if (njobs == 0) {
+    HIP_TRY(hipMemsetAsync(d_out_off, 0, sizeof(uint64_t), st));
+    return M4G_OK;
+  }
+
+  // job descriptors (re-uploaded only when the chunk layout changed)
+  bool same = b->last_off.size() == nchunks + 1 &&
+              std::memcmp(b->last_off.data(), chunk_off, (nchunks + 1) * 8) == 0;
+  if (!same) {
+    std::vector<Job> jobs(nchunks);
+    uint64_t chain_off = 0;
+    for (size_t c = 0; c < nchunks; c++) {
+      if (chunk_off[c + 1] < chunk_off[c]) return fail(M4G_ERR_BAD_PARAM, "chunk_off not ascending");
+      uint64_t n = chunk_off[c + 1] - chunk_off[c];
+      if (n > b->max_chunk_bytes)
+        return fail(M4G_ERR_TOO_LARGE, "chunk larger than the plan's max_chunk_bytes");
+      Job &J = jobs[c];
+      J.src_off = chunk_off[c];
+      J.chain_off = chain_off;
+      J.slot_off = (uint64_t)c * b->slot_cap;
+      J.start = 0;
+      J.len = (uint32_t)n;
+      J.seed_prev = 0;
+      J.slot_cap = (uint32_t)b->slot_cap;
+      chain_off += (n + 15) & ~(uint64_t)15;
+    }
+    // pageable source: the runtime stages it before returning, so `jobs` may die.
+    HIP_TRY(hipMemcpyAsync(b->d_jobs, jobs.data(), nchunks * sizeof(Job), hipMemcpyHostToDevice, st));
+    b->last_off.assign(chunk_off, chunk_off + nchunks + 1);
+  }
+
+  HIP_TRY(hipMemsetAsync(b->d_errors, 0, 4, st));
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
+  int rc = launch_find(b->p, d_src, b->d_chain, b->d_jobs, nullptr, njobs, b->d_slots, b->d_counts,
+                       b->d_errors, st, b->timing ? b->ev[1] : nullptr);
+  if (rc) return rc;
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
+
+  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, b->d_counts, d_out_off, njobs);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k4_compact, dim3((unsigned)njobs, K4_SPLIT), dim3(256), 0, st, b->d_slots,
+                     b->d_jobs, b->d_counts, d_out_off, reinterpret_cast<uint32_t *>(d_out),
+                     (uint64_t)out_cap);
+  HIP_TRY(hipGetLastError());
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
+
+  if (d_histos) {
+    static_assert(sizeof(m4g_histo) == 1024 * 4, "m4g_histo layout");
+    hipLaunchKernelGGL(k5_histograms, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
+                       b->d_slots, b->d_jobs, b->d_counts, b->d_pf,
+                       reinterpret_cast<uint32_t *>(d_histos));
+    HIP_TRY(hipGetLastError());
+  }
+  if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));
+  b->ran = true;
+  b->last_stream = st;
+  return M4G_OK;
+}
+
+extern "C" int m4g_batch_last_timings(m4g_batch *b, float *ms, int cap) {
+  if (!b || !ms || !b->timing || !b->ran) return 0;
+  if (hipSetDevice(b->device) != hipSuccess) return 0;
+  if (hipEventSynchronize(b->ev[4]) != hipSuccess) return 0;
+  int n = std::min(cap, 4);
+  for (int k = 0; k < n; k++)
+    if (hipEventElapsedTime(&ms[k], b->ev[k], b->ev[k + 1]) != hipSuccess) return k;
+  return n;
+}
+
+// ===========================================================================
+// host-memory batch over several devices
+// ===========================================================================
+namespace {
+struct DevPart {
+  int device = 0;
+  std::vector<size_t> chunks; // global chunk indices, ascending
+  std::vector<uint64_t> off;  // local offsets (chunks.size()+1)
+  m4g_batch *plan = nullptr;
+  uint8_t *d_src = nullptr;
+  m4g_match *d_out = nullptr;
+  uint64_t *d_out_off = nullptr;
+  m4g_histo *d_histos = nullptr;
+  hipStream_t st = nullptr;
+  std::vector<uint64_t> h_out_off;
+  size_t out_cap = 0;
+};
+
+void free_part(DevPart &P) {
+  (void)hipSetDevice(P.device);
+  if (P.st) (void)hipStreamSynchronize(P.st);
+  m4g_batch_destroy(P.plan);
+  (void)hipFree(P.d_src);
+  (void)hipFree(P.d_out);
+  (void)hipFree(P.d_out_off);
+  (void)hipFree(P.d_histos);
+  if (P.st) (void)hipStreamDestroy(P.st);
+}
+} // namespace
+
+extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
+                                          const uint64_t *chunk_off, size_t nchunks,
+                                          const int *devices, int ndevices, m4g_match *out,
+                                          uint64_t *out_off, size_t out_cap, m4g_histo *histos) {
+  Params p;
+  int rc = resolve_params(params, &p);
+  if (rc) return rc;
+  if (!chunk_off || !out_off || (!base && nchunks) || !devices || ndevices < 1)
+    return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  out_off[0] = 0;
+  if (nchunks == 0) return M4G_OK;
+  size_t max_bytes = 1;
+  for (size_t c = 0; c < nchunks; c++) {
+    if (chunk_off[c + 1] < chunk_off[c]) return fail(M4G_ERR_BAD_PARAM, "chunk_off not ascending");
+    max_bytes = std::max<size_t>(max_bytes, chunk_off[c + 1] - chunk_off[c]);
+  }
+  if (max_bytes > ((size_t)1 << 24)) return fail(M4G_ERR_TOO_LARGE, "chunk above 2^24 bytes");
+  for (int g = 0; g < ndevices; g++)
+    if ((rc = check_device(devices[g]))) return rc;
+
+  // pin the caller's buffers for the duration when possible (faster copies)
+  const size_t total = chunk_off[nchunks] - chunk_off[0];
+  bool pinned_in = total && hipHostRegister(const_cast<uint8_t *>(base) + chunk_off[0], total,
+                                            hipHostRegisterDefault) == hipSuccess;
+  (void)hipGetLastError();
+
+  std::vector<DevPart> parts(ndevices);
+  int64_t result = M4G_OK;
+  auto cleanup = [&]() {
+    for (auto &P : parts) free_part(P);
+    if (pinned_in) (void)hipHostUnregister(const_cast<uint8_t *>(base) + chunk_off[0]);
+  };
+#define BATCH_TRY(expr)                                                                \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      result = fail(M4G_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+      cleanup();                                                                       \
+      return result;                                                                   \
+    }                                                                                  \
+  } while (0)
+
+  // 1. shard: chunk c -> devices[c % ndevices]; upload + run, all devices async
+  for (int g = 0; g < ndevices; g++) {
+    DevPart &P = parts[g];
+    P.device = devices[g];
+    P.off.push_back(0);
+    for (size_t c = (size_t)g; c < nchunks; c += (size_t)ndevices) {
+      P.chunks.push_back(c);
+      uint64_t n = chunk_off[c + 1] - chunk_off[c];
+      P.off.push_back(P.off.back() + n);
+      P.out_cap += n / (size_t)p.min_length + 2;
+    }
+    if (P.chunks.empty()) continue;
+    BATCH_TRY(hipSetDevice(P.device));
+    BATCH_TRY(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking));
+    rc = m4g_batch_create(params, P.device, P.chunks.size(), max_bytes, &P.plan);
+    if (rc) {
+      cleanup();
+      return rc;
+    }
+    BATCH_TRY(hipMalloc(&P.d_src, P.off.back() + 64));
+    BATCH_TRY(hipMalloc(&P.d_out, P.out_cap * sizeof(m4g_match)));
+    BATCH_TRY(hipMalloc(&P.d_out_off, (P.chunks.size() + 1) * 8));
+    if (histos) BATCH_TRY(hipMalloc(&P.d_histos, P.chunks.size() * sizeof(m4g_histo)));
+    for (size_t k = 0; k < P.chunks.size(); k++) {
+      size_t c = P.chunks[k];
+      uint64_t n = chunk_off[c + 1] - chunk_off[c];
+      if (n)
+        BATCH_TRY(hipMemcpyAsync(P.d_src + P.off[k], base + chunk_off[c], n, hipMemcpyHostToDevice, P.st));
+    }
+    P.h_out_off.resize(P.chunks.size() + 1);
+    rc = m4g_batch_run_device(P.plan, P.d_src, P.off.data(), P.chunks.size(), P.d_out, P.d_out_off,
+                              P.out_cap, P.d_histos, P.st);
+    if (rc) {
+      cleanup();
+      return rc;
+    }
+    BATCH_TRY(hipMemcpyAsync(P.h_out_off.data(), P.d_out_off, (P.chunks.size() + 1) * 8,
+                             hipMemcpyDeviceToHost, P.st));
+  }
+
+  // 2. global offsets in chunk order
+  for (int g = 0; g < ndevices; g++) {
+    DevPart &P = parts[g];
+    if (P.chunks.empty()) continue;
+    BATCH_TRY(hipSetDevice(P.device));
+    BATCH_TRY(hipStreamSynchronize(P.st));
+    uint32_t err = 0;
+    BATCH_TRY(hipMemcpy(&err, P.plan->d_errors, 4, hipMemcpyDeviceToHost));
+    if (err) {
+      cleanup();
+      return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+    }
+  }
+  uint64_t run = 0;
+  for (size_t c = 0; c < nchunks; c++) {
+    DevPart &P = parts[c % (size_t)ndevices];
+    size_t k = c / (size_t)ndevices;
+    out_off[c] = run;
+    run += P.h_out_off[k + 1] - P.h_out_off[k];
+  }
+  out_off[nchunks] = run;
+  if (run > out_cap) {
+    cleanup();
+    return -(int64_t)run;
+  }
+
+  // 3. ordered concatenation on the host: each chunk's list lands at out_off[c]
+  bool pinned_out = run && hipHostRegister(out, run * sizeof(m4g_match), hipHostRegisterDefault) == hipSuccess;
+  (void)hipGetLastError();
+  for (size_t c = 0; c < nchunks; c++) {
+    DevPart &P = parts[c % (size_t)ndevices];
+    size_t k = c / (size_t)ndevices;
+    uint64_t cnt = P.h_out_off[k + 1] - P.h_out_off[k];
+    if (!cnt) continue;
+    hipError_t e = hipSetDevice(P.device);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(out + out_off[c], P.d_out + P.h_out_off[k], cnt * sizeof(m4g_match),
+                         hipMemcpyDeviceToHost, P.st);
+    if (e != hipSuccess) {
+      result = fail(M4G_ERR_HIP, std::string("D2H matches: ") + hipGetErrorString(e));
+      break;
+    }
+  }
+  if (result == M4G_OK && histos) {
+    for (int g = 0; g < ndevices && result == M4G_OK; g++) {
+      DevPart &P = parts[g];
+      if (P.chunks.empty()) continue;
+      std::vector<m4g_histo> tmp(P.chunks.size());
+      hipError_t e = hipSetDevice(P.device);
+      if (e == hipSuccess) e = hipStreamSynchronize(P.st);
+      if (e == hipSuccess)
+        e = hipMemcpy(tmp.data(), P.d_histos, tmp.size() * sizeof(m4g_histo), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) {
+        result = fail(M4G_ERR_HIP, std::string("D2H histograms: ") + hipGetErrorString(e));
+        break;
+      }
+      for (size_t k = 0; k < P.chunks.size(); k++) histos[P.chunks[k]] = tmp[k];
+    }
+  }
+  for (auto &P : parts)
+    if (P.st) {
+      (void)hipSetDevice(P.device);
+      (void)hipStreamSynchronize(P.st);
+    }
+  if (pinned_out) (void)hipHostUnregister(out);
+  cleanup();
+  return result;
+#undef BATCH_TRY
+}
+
+// ===========================================================================
+// streaming handle
+// ===========================================================================
+struct m4g_ctx {
+  int device = 0;
+  Params p{};
+  hipStream_t st = nullptr;
+  uint8_t *d_hist = nullptr;
+  uint32_t *d_chain = nullptr;
+  size_t cap = 0;      // capacity (bytes / chain entries)
+  int64_t hist_len = 0;
+  uint32_t *d_table = nullptr;
+  Rec *d_slots = nullptr;
+  size_t slot_cap = 0;
+  uint32_t *d_counts = nullptr; // [0] count, [1] errors
+  Job *d_job = nullptr;
+  Rec *h_recs = nullptr; // pinned staging
+  size_t h_recs_cap = 0;
+  uint32_t *h_counts = nullptr; // pinned, 2 words
+};
+
+extern "C" void m4g_destroy(m4g_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  (void)hipFree(c->d_hist);
+  (void)hipFree(c->d_chain);
+  (void)hipFree(c->d_table);
+  (void)hipFree(c->d_slots);
+  (void)hipFree(c->d_counts);
+  (void)hipFree(c->d_job);
+  if (c->h_recs) (void)hipHostFree(c->h_recs);
+  if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+extern "C" int m4g_create(const m4g_params *params, int device, m4g_ctx **out) {
+  if (!out) return fail(M4G_ERR_BAD_PARAM, "out is NULL");
+  *out = nullptr;
+  Params p;
+  int rc = resolve_params(params, &p);
+  if (rc) return rc;
+  if ((rc = check_device(device))) return rc;
+  HIP_TRY(hipSetDevice(device));
+  if ((rc = k1_prepare())) return rc;
+  m4g_ctx *c = new m4g_ctx();
+  c->device = device;
+  c->p = p;
+  const size_t tbytes = ((size_t)1 << p.table_bits) * 4;
+  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&c->d_table, tbytes) != hipSuccess || hipMalloc(&c->d_counts, 64) != hipSuccess ||
+      hipMalloc(&c->d_job, sizeof(Job)) != hipSuccess ||
+      hipHostMalloc(&c->h_counts, 64, hipHostMallocDefault) != hipSuccess ||
+      hipMemsetAsync(c->d_table, 0, tbytes, c->st) != hipSuccess) {
+    m4g_destroy(c);
+    return fail(M4G_ERR_NO_MEMORY, "allocating the streaming handle failed");
+  }
+  *out = c;
+  return M4G_OK;
+}
+
+extern "C" int m4g_reset(m4g_ctx *c) {
+  if (!c) return fail(M4G_ERR_BAD_PARAM, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  // m4.go:51-57
+  HIP_TRY(hipMemsetAsync(c->d_table, 0, ((size_t)1 << c->p.table_bits) * 4, c->st));
+  c->hist_len = 0;
+  return M4G_OK;
+}
+
+extern "C" int64_t m4g_history_len(m4g_ctx *c) { return c ? c->hist_len : -1; }
+
+namespace {
+int ctx_reserve(m4g_ctx *c, size_t need) {
+  if (need <= c->cap) return M4G_OK;
+  size_t nc = c->cap ? c->cap : ((size_t)1 << 20);
+  while (nc < need) nc *= 2;
+  uint8_t *nh = nullptr;
+  uint32_t *nch = nullptr;
+  if (hipMalloc(&nh, nc + 64) != hipSuccess || hipMalloc(&nch, nc * 4 + 64) != hipSuccess) {
+    (void)hipFree(nh);
+    (void)hipFree(nch);
+    return fail(M4G_ERR_NO_MEMORY, "growing the history buffer failed");
+  }
+  if (c->hist_len) {
+    HIP_TRY(hipMemcpyAsync(nh, c->d_hist, (size_t)c->hist_len, hipMemcpyDeviceToDevice, c->st));
+    HIP_TRY(hipMemcpyAsync(nch, c->d_chain, (size_t)c->hist_len * 4, hipMemcpyDeviceToDevice, c->st));
+  }
+  HIP_TRY(hipStreamSynchronize(c->st));
+  (void)hipFree(c->d_hist);
+  (void)hipFree(c->d_chain);
+  c->d_hist = nh;
+  c->d_chain = nch;
+  c->cap = nc;
+  return M4G_OK;
+}
+} // namespace
+
+extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
+                                    uint32_t seed_prev_distance, m4g_match *out, size_t out_cap) {
+  if (!c || (!src && n) || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  const Params &p = c->p;
+  if ((uint64_t)c->hist_len + n >= ((uint64_t)1 << 31))
+    return fail(M4G_ERR_TOO_LARGE, "history + block must stay below 2^31 bytes");
+  const size_t need = n / (size_t)p.min_length + 2;
+  if (out_cap < need && n != 0) {
+    // refuse before touching any state, so the handle is unchanged
+    g_last_error = "out_cap below n/min_length + 2";
+    return -(int64_t)need;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+
+  // m4.go:82-99: slide.  delta > MaxDistance here, so source and destination of
+  // the copies do not overlap.
+  if (c->hist_len > 2 * (int64_t)p.max_distance) {
+    const int64_t delta = c->hist_len - p.max_distance;
+    HIP_TRY(hipMemcpyAsync(c->d_hist, c->d_hist + delta, (size_t)p.max_distance,
+                           hipMemcpyDeviceToDevice, c->st));
+    HIP_TRY(hipMemcpyAsync(c->d_chain, c->d_chain + delta, (size_t)p.max_distance * 4,
+                           hipMemcpyDeviceToDevice, c->st));
+    const uint32_t tn = 1u << p.table_bits;
+    hipLaunchKernelGGL(ks_rebase_table, dim3((tn + 255) / 256), dim3(256), 0, c->st, c->d_table, tn,
+                       (uint32_t)delta);
+    HIP_TRY(hipGetLastError());
+    c->hist_len = p.max_distance;
+  }
+  if (n == 0) return 0; // m4.go:112,276: nothing inserted, nothing emitted
+
+  int rc = ctx_reserve(c, (size_t)c->hist_len + n);
+  if (rc) return rc;
+  if (c->slot_cap < need) {
+    (void)hipFree(c->d_slots);
+    c->d_slots = nullptr;
+    if (c->h_recs) (void)hipHostFree(c->h_recs);
+    c->h_recs = nullptr;
+    size_t nc = std::max(need, (size_t)4096);
+    if (hipMalloc(&c->d_slots, nc * sizeof(Rec)) != hipSuccess ||
+        hipHostMalloc(&c->h_recs, nc * sizeof(Rec), hipHostMallocDefault) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "allocating the match slot failed");
+    c->slot_cap = nc;
+  }
+
+  // m4.go:101-107: append src
+  HIP_TRY(hipMemcpyAsync(c->d_hist + c->hist_len, src, n, hipMemcpyHostToDevice, c->st));
+  Job J{};
+  J.src_off = 0;
+  J.chain_off = 0;
+  J.slot_off = 0;
+  J.start = (uint32_t)c->hist_len;
+  J.len = (uint32_t)(c->hist_len + (int64_t)n);
+  J.seed_prev = seed_prev_distance;
+  J.slot_cap = (uint32_t)c->slot_cap;
+  HIP_TRY(hipMemcpyAsync(c->d_job, &J, sizeof(Job), hipMemcpyHostToDevice, c->st));
+  HIP_TRY(hipMemsetAsync(c->d_counts, 0, 8, c->st));
+  // positions in [start, len-7) that K1 does not visit keep chain = 0 only if
+  // cleared: the last 7 of every block are never inserted (m4.go:112).
+  HIP_TRY(hipMemsetAsync(c->d_chain + c->hist_len, 0, n * 4, c->st));
+  rc = launch_find(p, c->d_hist, c->d_chain, c->d_job, c->d_table, 1, c->d_slots, c->d_counts,
+                   c->d_counts + 1, c->st, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  c->hist_len += (int64_t)n;
+  if (c->h_counts[1]) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+  const uint32_t cnt = c->h_counts[0];
+  if (cnt > c->slot_cap) return fail(M4G_ERR_HIP, "internal: match slot overflow");
+  if (cnt) {
+    HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_slots, (size_t)cnt * sizeof(Rec), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    for (uint32_t k = 0; k < cnt; k++) {
+      out[k].unmatched = c->h_recs[k].unmatched;
+      out[k].length = c->h_recs[k].length;
+      out[k].distance = c->h_recs[k].distance;
+    }
+  }
+  return (int64_t)cnt;
+}
+
+extern "C" int m4g_debug_dump_tables(m4g_ctx *c, uint32_t *table, uint32_t *chain, size_t chain_cap) {
+  if (!c) return fail(M4G_ERR_BAD_PARAM, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  if (table)
+    HIP_TRY(hipMemcpy(table, c->d_table, ((size_t)1 << c->p.table_bits) * 4, hipMemcpyDeviceToHost));
+  if (chain && c->hist_len) {
+    size_t k = std::min(chain_cap, (size_t)c->hist_len);
+    HIP_TRY(hipMemcpy(chain, c->d_chain, k * 4, hipMemcpyDeviceToHost));
+  }
+  return M4G_OK;
+}

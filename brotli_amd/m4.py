@@ -1,0 +1,320 @@
+"""Host-side mirror of the reference's plugin interface over libm4g.so.
+
+``M4`` has the exported fields of ``matchfinder.M4`` (matchfinder/m4.go:15-43)
+and the two methods of ``matchfinder.MatchFinder`` (matchfinder/matchfinder.go:23-30):
+``FindMatches(dst, src)`` and ``Reset()``.  ``Writer`` restates
+``matchfinder.Writer`` (matchfinder/matchfinder.go:44-103) so the parity tests
+read like the reference's ``test()`` helper (brotli_test.go:626-649).
+
+Everything here calls the C-ABI of include/m4g.h through ctypes; there is no
+Python or CPU implementation of the match finder in this package.  Loading
+fails loudly when the HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm4g.so")
+
+M4G_OK = 0
+ERR_BASE = -1000000
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("max_distance", ctypes.c_int32), ("min_length", ctypes.c_int32),
+                ("hash_len", ctypes.c_int32), ("table_bits", ctypes.c_int32),
+                ("chain_length", ctypes.c_int32), ("distance_bit_cost", ctypes.c_int32)]
+
+
+EXPORTS = [
+    "m4g_strerror", "m4g_last_error", "m4g_device_count", "m4g_create", "m4g_destroy",
+    "m4g_reset", "m4g_find_matches", "m4g_debug_dump_tables", "m4g_history_len",
+    "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_find_matches_batch",
+    "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
+]
+
+_LIB = None
+
+
+class M4GError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libm4g.so (built by __graft_entry__.build()); raises if absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise M4GError(f"{LIB_PATH} is missing: build it with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'`. "
+                           "There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch wheels bundle their own
+        # libamdhip64.so.7.  If libm4g.so were loaded first it would pull in the
+        # system runtime and a later `import torch` would bring a second HSA
+        # runtime into the process, which then sees no GPU.  Importing torch
+        # first makes the dynamic linker resolve our NEEDED libamdhip64.so.7
+        # to the runtime torch already loaded (same SONAME).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)
+        L.m4g_strerror.argtypes = [ctypes.c_int]
+        L.m4g_strerror.restype = ctypes.c_char_p
+        L.m4g_last_error.restype = ctypes.c_char_p
+        L.m4g_device_count.restype = ctypes.c_int
+        L.m4g_create.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.POINTER(vp)]
+        L.m4g_destroy.argtypes = [vp]
+        L.m4g_destroy.restype = None
+        L.m4g_reset.argtypes = [vp]
+        L.m4g_find_matches.argtypes = [vp, vp, sz, ctypes.c_uint32, vp, sz]
+        L.m4g_find_matches.restype = ctypes.c_int64
+        L.m4g_debug_dump_tables.argtypes = [vp, vp, vp, sz]
+        L.m4g_history_len.argtypes = [vp]
+        L.m4g_history_len.restype = ctypes.c_int64
+        L.m4g_batch_create.argtypes = [ctypes.POINTER(Params), ctypes.c_int, sz, sz,
+                                       ctypes.POINTER(vp)]
+        L.m4g_batch_destroy.argtypes = [vp]
+        L.m4g_batch_destroy.restype = None
+        L.m4g_batch_run_device.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp]
+        L.m4g_find_matches_batch.argtypes = [ctypes.POINTER(Params), vp, vp, sz, vp, ctypes.c_int,
+                                             vp, vp, sz, vp]
+        L.m4g_find_matches_batch.restype = ctypes.c_int64
+        L.m4g_batch_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+        L.m4g_batch_set_timing.argtypes = [vp, ctypes.c_int]
+        L.m4g_batch_set_timing.restype = None
+        L.m4g_host_alloc.argtypes = [sz]
+        L.m4g_host_alloc.restype = vp
+        L.m4g_host_free.argtypes = [vp]
+        L.m4g_host_free.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int, what: str):
+    if rc < ERR_BASE:
+        L = lib()
+        raise M4GError(f"{what}: {L.m4g_strerror(int(rc)).decode()} "
+                       f"({L.m4g_last_error().decode()})")
+
+
+def _as_u8(src) -> np.ndarray:
+    if isinstance(src, np.ndarray):
+        return np.ascontiguousarray(src, dtype=np.uint8)
+    return np.frombuffer(bytes(src), dtype=np.uint8)
+
+
+def _params(MaxDistance, MinLength, HashLen, TableBits, ChainLength, DistanceBitCost) -> Params:
+    return Params(MaxDistance, MinLength, HashLen, TableBits, ChainLength, DistanceBitCost)
+
+
+Match = Tuple[int, int, int]  # (Unmatched, Length, Distance)  matchfinder.go:16-20
+
+
+class M4:
+    """``matchfinder.M4`` on an MI355X.  Zero-valued fields take the reference's
+    defaults (m4.go:64-75)."""
+
+    def __init__(self, MaxDistance=0, MinLength=0, HashLen=0, TableBits=0, ChainLength=0,
+                 DistanceBitCost=0, device: int = 0):
+        self.MaxDistance = MaxDistance
+        self.MinLength = MinLength
+        self.HashLen = HashLen
+        self.TableBits = TableBits
+        self.ChainLength = ChainLength
+        self.DistanceBitCost = DistanceBitCost
+        self.device = device
+        self._h = None
+
+    # created lazily on first use, like the reference allocates its table on
+    # the first FindMatches call (m4.go:76-78)
+    def _handle(self):
+        if self._h is None:
+            h = ctypes.c_void_p()
+            p = _params(self.MaxDistance, self.MinLength, self.HashLen, self.TableBits,
+                        self.ChainLength, self.DistanceBitCost)
+            _check(lib().m4g_create(ctypes.byref(p), self.device, ctypes.byref(h)), "m4g_create")
+            self._h = h
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().m4g_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def Reset(self):
+        """matchfinder.M4.Reset (m4.go:51-57)."""
+        if self._h is not None:
+            _check(lib().m4g_reset(self._h), "m4g_reset")
+
+    def find_matches(self, src, seed_prev_distance: int = 0) -> np.ndarray:
+        """One FindMatches call; returns an (M, 3) uint32 array."""
+        a = _as_u8(src)
+        min_len = self.MinLength or 4
+        cap = a.size // min_len + 2
+        out = np.empty((cap, 3), dtype=np.uint32)
+        r = lib().m4g_find_matches(self._handle(), a.ctypes.data if a.size else None, a.size,
+                                   seed_prev_distance, out.ctypes.data, cap)
+        _check(r, "m4g_find_matches")
+        if r < 0:
+            raise M4GError(f"m4g_find_matches: out_cap too small, need {-r}")
+        return out[:r].copy()
+
+    def FindMatches(self, dst: List[Match], src) -> List[Match]:
+        """matchfinder.MatchFinder.FindMatches: append to dst, return dst."""
+        seed = dst[-1][2] if dst else 0
+        if dst and seed == 0:
+            raise M4GError("dst ends in a Match with Distance 0; the reference's repeat probe "
+                           "degenerates on that input (SURVEY.md section 3.2) - unsupported")
+        m = self.find_matches(src, seed)
+        dst.extend((int(u), int(l), int(d)) for u, l, d in m.tolist())
+        return dst
+
+    def dump_tables(self) -> Tuple[np.ndarray, np.ndarray]:
+        L = lib()
+        h = self._handle()
+        tb = self.TableBits or 17
+        n = int(L.m4g_history_len(h))
+        table = np.zeros(1 << tb, dtype=np.uint32)
+        chain = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(L.m4g_debug_dump_tables(h, table.ctypes.data, chain.ctypes.data, n),
+               "m4g_debug_dump_tables")
+        return table, chain[:n]
+
+
+class AutoReset:
+    """matchfinder.AutoReset (matchfinder/textencoder.go:46-53)."""
+
+    def __init__(self, mf):
+        self.MatchFinder = mf
+
+    def Reset(self):
+        self.MatchFinder.Reset()
+
+    def FindMatches(self, dst, src):
+        self.MatchFinder.Reset()
+        return self.MatchFinder.FindMatches(dst, src)
+
+
+class Writer:
+    """matchfinder.Writer (matchfinder/matchfinder.go:44-103).  `Encoder` is any
+    object with Encode(src, matches, last_block) -> bytes and Reset(); the
+    bit-stream encoder stays on the CPU and is not part of this package."""
+
+    def __init__(self, Dest, MatchFinder, Encoder, BlockSize: int = 0):
+        self.Dest = Dest
+        self.MatchFinder = MatchFinder
+        self.Encoder = Encoder
+        self.BlockSize = BlockSize
+        self._in = bytearray()
+
+    def Write(self, p) -> int:
+        p = bytes(p)
+        if self.BlockSize == 0:
+            self._write_block(p, False)
+            return len(p)
+        self._in += p
+        pos = 0
+        while pos + self.BlockSize <= len(self._in):
+            self._write_block(bytes(self._in[pos:pos + self.BlockSize]), False)
+            pos += self.BlockSize
+        if pos:
+            del self._in[:pos]
+        return len(p)
+
+    def _write_block(self, p: bytes, last: bool):
+        matches = self.MatchFinder.FindMatches([], p)
+        m = np.array(matches, dtype=np.uint32).reshape(-1, 3)
+        self.Dest.write(self.Encoder.Encode(p, m, last))
+
+    def Close(self):
+        self._write_block(bytes(self._in), True)
+        self._in.clear()
+
+    def Reset(self, newDest):
+        self.MatchFinder.Reset()
+        self.Encoder.Reset()
+        self._in.clear()
+        self.Dest = newDest
+
+
+class BatchPlan:
+    """Independent chunks, device resident (m4g_batch_*).  Tensors are torch
+    CUDA(HIP) tensors; torch is used only as the device allocator."""
+
+    def __init__(self, max_chunks: int, max_chunk_bytes: int, device: int = 0, **m4_fields):
+        self.params = _params(m4_fields.get("MaxDistance", 0), m4_fields.get("MinLength", 0),
+                              m4_fields.get("HashLen", 0), m4_fields.get("TableBits", 0),
+                              m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
+        self.device = device
+        self.max_chunks = max_chunks
+        self.max_chunk_bytes = max_chunk_bytes
+        h = ctypes.c_void_p()
+        _check(lib().m4g_batch_create(ctypes.byref(self.params), device, max_chunks,
+                                      max_chunk_bytes, ctypes.byref(h)), "m4g_batch_create")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().m4g_batch_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def set_timing(self, on: bool):
+        lib().m4g_batch_set_timing(self._h, 1 if on else 0)
+
+    def last_timings(self) -> List[float]:
+        ms = (ctypes.c_float * 4)()
+        n = lib().m4g_batch_last_timings(self._h, ms, 4)
+        return [float(ms[k]) for k in range(n)]
+
+    def run(self, d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0):
+        """d_src: uint8 tensor; chunk_off: host uint64 array (nchunks+1);
+        d_out: int32/uint32-view tensor with 3*out_cap elements; d_out_off:
+        int64 tensor (nchunks+1); d_histos: optional int32 tensor (nchunks*1024)."""
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        n = off.size - 1
+        out_cap = d_out.numel() * d_out.element_size() // 12
+        rc = lib().m4g_batch_run_device(self._h, d_src.data_ptr(), off.ctypes.data, n,
+                                        d_out.data_ptr(), d_out_off.data_ptr(), out_cap,
+                                        d_histos.data_ptr() if d_histos is not None else None,
+                                        stream if stream else None)
+        _check(rc, "m4g_batch_run_device")
+
+
+def find_matches_batch(base, chunk_off: Sequence[int], devices: Sequence[int] = (0,),
+                       want_histos: bool = False, **m4_fields):
+    """Host-memory batch (m4g_find_matches_batch): returns (matches[M,3],
+    out_off[nchunks+1], histos[nchunks,1024] or None)."""
+    a = _as_u8(base)
+    off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+    n = off.size - 1
+    p = _params(m4_fields.get("MaxDistance", 0), m4_fields.get("MinLength", 0),
+                m4_fields.get("HashLen", 0), m4_fields.get("TableBits", 0),
+                m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
+    min_len = p.min_length or 4
+    cap = int(sum(int(off[c + 1] - off[c]) // min_len + 2 for c in range(n))) + 1
+    out = np.empty((cap, 3), dtype=np.uint32)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    histos = np.zeros((max(n, 1), 1024), dtype=np.uint32) if want_histos else None
+    devs = (ctypes.c_int * len(devices))(*devices)
+    r = lib().m4g_find_matches_batch(ctypes.byref(p), a.ctypes.data if a.size else None,
+                                     off.ctypes.data, n, devs, len(devices), out.ctypes.data,
+                                     out_off.ctypes.data, cap,
+                                     histos.ctypes.data if want_histos else None)
+    _check(r, "m4g_find_matches_batch")
+    if r < 0:
+        raise M4GError(f"m4g_find_matches_batch: out_cap too small, need {-r}")
+    total = int(out_off[n])
+    return out[:total].copy(), out_off, (histos[:n] if want_histos else None)

@@ -1,0 +1,177 @@
+/*
+ * m4g.h -- C-ABI of libm4g.so: an MI355X (gfx950) implementation of the
+ * andybalholm/brotli `matchfinder.M4` match finder and of the histogram pass
+ * of `brotli.Encoder`, for use behind the reference's own plugin interface
+ *
+ *     type MatchFinder interface {                 // matchfinder/matchfinder.go:23-30
+ *         FindMatches(dst []Match, src []byte) []Match
+ *         Reset()
+ *     }
+ *
+ * Plain C types only (no torch / HIP types in any signature).  The reference
+ * is pure Go with no FFI today; these are the entry points a cgo shim binds
+ * (INTEGRATION.md shows that shim).  Each declaration cites the reference
+ * code it replaces (paths relative to the reference checkout).
+ *
+ * Threading: a handle (m4g_ctx / m4g_batch) may be used by one thread at a
+ * time; distinct handles are independent.  Every entry point selects its HIP
+ * device itself, so callers whose OS thread changes between calls (Go
+ * goroutines) need no device bookkeeping.
+ *
+ * There is NO CPU backend: every entry point runs hand-written HIP kernels
+ * and returns M4G_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef M4G_H
+#define M4G_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* matchfinder.Match (matchfinder/matchfinder.go:16-20).  Go's three ints are
+ * 64-bit; all values on this path are < 2^32, the shim widens them. */
+typedef struct {
+  uint32_t unmatched; /* Match.Unmatched */
+  uint32_t length;    /* Match.Length (0 only for a trailing literal run) */
+  uint32_t distance;  /* Match.Distance */
+} m4g_match;
+
+/* The exported fields of matchfinder.M4 (matchfinder/m4.go:15-43).
+ * 0 means "reference default", exactly as in m4.go:64-75:
+ * MaxDistance 65535, MinLength 4, HashLen 6, TableBits 17. */
+typedef struct {
+  int32_t max_distance;
+  int32_t min_length;
+  int32_t hash_len;
+  int32_t table_bits;
+  int32_t chain_length;
+  int32_t distance_bit_cost;
+} m4g_params;
+
+/* The three histograms built by pass 1 of brotli.Encoder.Encode
+ * (encoder.go:33-35: literalHisto, commandHisto, distanceHisto). */
+typedef struct {
+  uint32_t lit[256];
+  uint32_t cmd[704];
+  uint32_t dist[64];
+} m4g_histo;
+
+typedef struct m4g_ctx m4g_ctx;     /* one streaming M4 (one Go `*M4`) */
+typedef struct m4g_batch m4g_batch; /* reusable plan for independent chunks */
+
+enum {
+  M4G_OK = 0,
+  M4G_ERR_NO_DEVICE = -1000001, /* no usable HIP device / extension kernels */
+  M4G_ERR_BAD_PARAM = -1000002,
+  M4G_ERR_HIP = -1000003,       /* a HIP call failed; see m4g_last_error() */
+  M4G_ERR_TOO_LARGE = -1000004, /* input beyond the limits stated below */
+  M4G_ERR_NO_MEMORY = -1000005,
+  M4G_ERR_REPEAT_RANGE = -1000006 /* seeded repeat distance reaches before the
+                                     history start (the Go code would panic) */
+};
+/* Count-returning entry points use values >= -1000000 for "-(needed)". */
+
+/* Human-readable text for an error code. */
+const char *m4g_strerror(int code);
+/* Detail of the last failure on the calling thread (HIP error text etc.). */
+const char *m4g_last_error(void);
+/* Number of usable gfx950 devices (0 when none / no driver). */
+int m4g_device_count(void);
+
+/* ---- streaming: one call == one M4.FindMatches ------------------------- */
+
+/* Replaces: constructing `&matchfinder.M4{...}` (m4.go:15-49).
+ * device >= 0 selects the HIP device.  device < 0 is rejected
+ * (M4G_ERR_NO_DEVICE): there is deliberately no CPU fallback. */
+int m4g_create(const m4g_params *params, int device, m4g_ctx **out);
+void m4g_destroy(m4g_ctx *ctx);
+
+/* Replaces: M4.Reset (m4.go:51-57). */
+int m4g_reset(m4g_ctx *ctx);
+
+/* Replaces: M4.FindMatches(dst, src) (m4.go:63-283) with the same streaming
+ * semantics: the handle keeps history / hash table / chain between calls,
+ * including the history slide of m4.go:82-99.  `src` (host memory, borrowed
+ * for the call) is appended to the history; the matches of this block are
+ * written to `out`.
+ *   seed_prev_distance: Distance of the last element of the caller's `dst`
+ *       when `dst` is non-empty (m4.go:129-130 reads it for the repeat
+ *       probe); 0 when dst is empty -- matchfinder.Writer always passes
+ *       w.matches[:0] (matchfinder.go:83).
+ *   returns the number of matches (>= 0), or an M4G_ERR_*.  out_cap must be
+ *       at least n/min_length + 2 (the worst case); a smaller out_cap returns
+ *       -(that bound) before anything is touched, so the handle is unchanged.
+ * Limit: n plus retained history must stay below 2^31 bytes. */
+int64_t m4g_find_matches(m4g_ctx *ctx, const uint8_t *src, size_t n,
+                         uint32_t seed_prev_distance, m4g_match *out,
+                         size_t out_cap);
+
+/* Debug / parity: copy the handle's hash table (1<<table_bits entries) and
+ * chain deltas (one per history byte; reference keeps them only when
+ * ChainLength > 0, this implementation always) to host memory.  Either
+ * pointer may be NULL.  (m4.go:45-46 `table`, `chain`.) */
+int m4g_debug_dump_tables(m4g_ctx *ctx, uint32_t *table, uint32_t *chain,
+                          size_t chain_cap);
+/* Current history length (len(q.history), m4.go:48). */
+int64_t m4g_history_len(m4g_ctx *ctx);
+
+/* ---- batch of independent chunks (throughput path) ---------------------
+ * Semantics per chunk: `m.Reset(); m.FindMatches(nil, chunk)` == the
+ * reference's matchfinder.AutoReset wrapper (matchfinder/textencoder.go:46-53),
+ * followed (optionally) by pass 1 of brotli.Encoder.Encode (encoder.go:44-105)
+ * on that chunk's matches.
+ */
+
+/* Plan + device workspace for up to max_chunks chunks of up to
+ * max_chunk_bytes bytes each (max_chunk_bytes <= 2^24, the largest
+ * meta-block brotli.Encoder accepts, compress_fragment_two_pass.go:232). */
+int m4g_batch_create(const m4g_params *params, int device, size_t max_chunks,
+                     size_t max_chunk_bytes, m4g_batch **out);
+void m4g_batch_destroy(m4g_batch *b);
+
+/* Device-resident form: every pointer prefixed d_ is device memory on the
+ * plan's device; chunk_off is HOST memory (nchunks+1 ascending byte offsets
+ * into d_src).  Work is enqueued on `hip_stream` (a hipStream_t, NULL = the
+ * default stream) and the call returns without synchronising.
+ *   d_out      : out_cap records; chunk c's matches land at
+ *                d_out[d_out_off[c] .. d_out_off[c+1]) in chunk order.
+ *   d_out_off  : nchunks+1 uint64 (exclusive prefix sum of match counts).
+ *   d_histos   : nullable; one m4g_histo per chunk.
+ * If the total match count exceeds out_cap nothing is written past out_cap
+ * and d_out_off still holds the true offsets (the caller can detect it). */
+int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src,
+                         const uint64_t *chunk_off, size_t nchunks,
+                         m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
+                         m4g_histo *d_histos, void *hip_stream);
+
+/* Host-memory form over one or more devices: chunk c goes to
+ * devices[c % ndevices]; per-chunk Match lists and histograms come back over
+ * pinned async copies and are concatenated in chunk order on the host.
+ * No inter-GPU communication.  Returns M4G_OK, or -(needed) when out_cap is
+ * too small, or an M4G_ERR_*. */
+int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
+                               const uint64_t *chunk_off, size_t nchunks,
+                               const int *devices, int ndevices, m4g_match *out,
+                               uint64_t *out_off, size_t out_cap,
+                               m4g_histo *histos);
+
+/* Per-stage kernel time of the plan's most recent run, measured with HIP
+ * events on the stream the kernels ran on.  Synchronises that stream.
+ * ms[0] = chain build (K1), ms[1] = parse (K3), ms[2] = compaction (K4),
+ * ms[3] = histograms (K5).  Returns the number of stages written. */
+int m4g_batch_last_timings(m4g_batch *b, float *ms, int cap);
+/* Enable (1) / disable (0) the event recording used by the call above. */
+void m4g_batch_set_timing(m4g_batch *b, int enabled);
+
+/* Host staging helpers for callers without a HIP binding (bench.py uses
+ * torch tensors instead; the Go shim uses these): pinned host memory. */
+void *m4g_host_alloc(size_t bytes);
+void m4g_host_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M4G_H */

@@ -1,0 +1,79 @@
+// tests/sim/parse_sim.cpp -- HOST build of brotli_amd/csrc/m4_parse.h for the
+// CPU test-suite.  TEST HARNESS ONLY: it lets `pytest -m "not gpu"` check the
+// parse state machine (and the sub-block speculation logic built on it)
+// against the oracle without a GPU.  It is not linked into libm4g.so and no
+// product code loads it.
+//
+// The chain array that kernel K1 produces on the GPU is produced here by a
+// plain sequential table sweep (m4.go:140-147).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../brotli_amd/csrc/m4_parse.h"
+#if __has_include("../../brotli_amd/csrc/m4_spec.h")
+#include "../../brotli_amd/csrc/m4_spec.h"
+#define HAVE_SPEC 1
+#endif
+
+using namespace m4g;
+
+namespace {
+struct VecSink {
+  std::vector<Rec> v;
+  void push(const Rec &r) { v.push_back(r); }
+};
+
+void build_chain(const uint8_t *src, int32_t start, int32_t len, int hash_len, int table_bits,
+                 std::vector<uint32_t> &table, uint32_t *chain) {
+  const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
+  for (int32_t i = start; i < len - 7; i++) {
+    uint64_t h = ((ld64(src + i) & mask) * 0x1E35A7BD1E35A7BDull) >> (64 - table_bits);
+    uint32_t c = table[h];
+    table[h] = (uint32_t)i;
+    chain[i] = c ? (uint32_t)i - c : 0;
+  }
+}
+} // namespace
+
+extern "C" {
+
+// One fresh-state FindMatches over `src` (P0 semantics), serial parse.
+// out: 4 u32 per record (unmatched, length, distance, lit_start).
+int64_t sim_find_matches(const uint8_t *src, int32_t n, int max_distance, int min_length,
+                         int hash_len, int table_bits, int chain_length, int distance_bit_cost,
+                         uint32_t seed_prev, uint32_t *out, int64_t out_cap) {
+  ParseParams P{max_distance, min_length, hash_len, chain_length, distance_bit_cost};
+  std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
+  build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
+  VecSink sink;
+  ParseState S;
+  state_init(S, 0, seed_prev);
+  parse_range(src, n, chain.data(), P, S, n - 7, sink);
+  parse_finish(n, P, S, sink);
+  if ((int64_t)sink.v.size() > out_cap) return -(int64_t)sink.v.size();
+  if (!sink.v.empty()) std::memcpy(out, sink.v.data(), sink.v.size() * sizeof(Rec));
+  return S.error ? INT64_MIN : (int64_t)sink.v.size();
+}
+
+#ifdef HAVE_SPEC
+// Same result through the speculative sub-block scheme of m4_spec.h, executed
+// sequentially on the host exactly as kernels K3a/K3b do on the device.
+// stats[0] = sub-blocks, stats[1] = sub-blocks that synchronised,
+// stats[2] = positions re-parsed by the stitcher.
+int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, int min_length,
+                              int hash_len, int table_bits, int chain_length,
+                              int distance_bit_cost, uint32_t seed_prev, int32_t sub_block,
+                              uint32_t *out, int64_t out_cap, int64_t *stats) {
+  ParseParams P{max_distance, min_length, hash_len, chain_length, distance_bit_cost};
+  std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
+  build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
+  std::vector<Rec> result;
+  uint32_t err = 0;
+  spec_host_run(src, n, chain.data(), P, 0, seed_prev, sub_block, result, stats, &err);
+  if ((int64_t)result.size() > out_cap) return -(int64_t)result.size();
+  if (!result.empty()) std::memcpy(out, result.data(), result.size() * sizeof(Rec));
+  return err ? INT64_MIN : (int64_t)result.size();
+}
+#endif
+}

@@ -1,0 +1,149 @@
+"""GPU parity: the HIP path (through the C-ABI) vs the CPU oracle, bit-exact."""
+import io
+
+import numpy as np
+import pytest
+
+from brotli_amd import m4, synth
+from cases import KATS, PARAMS_D, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs
+from oracle_lib import OracleEncoder, OracleM4, brotli_decompress, histograms, replay
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    a = np.asarray(a, dtype=np.uint32).reshape(-1, 3)
+    b = np.asarray(b, dtype=np.uint32).reshape(-1, 3)
+    return a.shape == b.shape and bool((a == b).all())
+
+
+def test_kats_streaming_api():
+    inputs = edge_inputs()
+    for name, exp in KATS.items():
+        got = m4.M4().find_matches(inputs[name])
+        assert same(got, exp), name
+
+
+@pytest.mark.parametrize("kw", [PARAMS_G, PARAMS_D] + PARAMS_REF_TESTS + PARAMS_MISC,
+                         ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()) or "defaults")
+def test_edge_inputs_fresh_state(kw):
+    """P0: fresh handle per input (== AutoReset), every edge input."""
+    g = m4.M4(**kw)
+    for name, data in edge_inputs().items():
+        g.Reset()
+        got = g.find_matches(data)
+        ref = OracleM4(**kw).FindMatches(data)
+        assert same(got, ref), f"{name}: {len(got)} vs {len(ref)} matches"
+        assert replay(got, data) == data
+
+
+@pytest.mark.parametrize("kw", [PARAMS_G, dict(MaxDistance=1 << 18, DistanceBitCost=66, ChainLength=16),
+                                dict(MaxDistance=40000, ChainLength=4, HashLen=5, DistanceBitCost=66)],
+                         ids=["G", "chain16", "slide40000"])
+def test_streaming_blocks_p1(kw):
+    """P1: one handle, successive blocks without Reset (matchfinder.Writer),
+    including the history slide (m4.go:82-99) for the small-window set."""
+    data = synth.text(700000, 5)
+    bs = 1 << 16
+    g, o = m4.M4(**kw), OracleM4(**kw)
+    pos = 0
+    while pos < len(data):
+        blk = data[pos:pos + bs]
+        assert same(g.find_matches(blk), o.FindMatches(blk)), f"block at {pos}"
+        pos += bs
+    # Close() with an empty remainder
+    assert same(g.find_matches(b""), o.FindMatches(b""))
+    # chain/table parity (K1) after the last block
+    table, chain = g.dump_tables()
+    assert (table == o.dump_table()).all()
+    if kw.get("ChainLength", 0) > 0:
+        assert (chain == o.dump_chain()).all()
+    # Reset then reuse: determinism pattern of brotli_test.go:135-149
+    g.Reset()
+    o.Reset()
+    assert same(g.find_matches(data[:bs]), o.FindMatches(data[:bs]))
+
+
+def test_roundtrip_through_writer():
+    """brotli_test.go:626-649 `test()`: Writer{M4, Encoder, 1<<16} -> decoder."""
+    data = synth.text(567198, 1)  # size of testdata/Isaac.Newton-Opticks.txt
+    for kw in PARAMS_REF_TESTS[:2]:
+        buf = io.BytesIO()
+        w = m4.Writer(buf, m4.M4(**kw), OracleEncoder(), 1 << 16)
+        w.Write(data)
+        w.Close()
+        assert brotli_decompress(buf.getvalue(), len(data)) == data
+        ref_stream, _ = OracleM4(**kw).compress(data, 1 << 16)
+        assert buf.getvalue() == ref_stream
+
+
+def _run_batch(host, n, nchunks, kw, histos=True):
+    import torch
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(host).to(dev)
+    plan = m4.BatchPlan(nchunks, n, 0, **kw)
+    off = np.arange(nchunks + 1, dtype=np.uint64) * n
+    min_len = kw.get("MinLength", 0) or 4
+    d_out = torch.empty(3 * (n // min_len + 2) * nchunks, dtype=torch.int32, device=dev)
+    d_off = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
+    d_h = torch.empty(nchunks * 1024, dtype=torch.int32, device=dev) if histos else None
+    plan.run(d_src, off, d_out, d_off, d_h)
+    torch.cuda.synchronize()
+    o = d_off.cpu().numpy()
+    out = d_out.cpu().numpy().view(np.uint32).reshape(-1, 3)
+    h = d_h.cpu().numpy().view(np.uint32).reshape(nchunks, 1024) if histos else None
+    return out, o, h
+
+
+@pytest.mark.parametrize("kind", ["text", "log"])
+@pytest.mark.parametrize("kw", [PARAMS_G, PARAMS_D], ids=["G", "D"])
+def test_batch_device_vs_oracle(kind, kw):
+    n, nchunks = 1 << 18, 12
+    host = np.empty(n * nchunks, dtype=np.uint8)
+    synth.fill(host, n, 100, kind, 8)
+    out, o, h = _run_batch(host, n, nchunks, kw)
+    for c in range(nchunks):
+        chunk = host[c * n:(c + 1) * n]
+        ref = OracleM4(**kw).FindMatches(chunk)
+        assert same(out[o[c]:o[c + 1]], ref), f"chunk {c}"
+        lit, cmd, dist, _, _ = histograms(chunk, ref)
+        assert (h[c, :256] == lit).all(), f"chunk {c} literal histogram"
+        assert (h[c, 256:960] == cmd).all(), f"chunk {c} command histogram"
+        assert (h[c, 960:] == dist).all(), f"chunk {c} distance histogram"
+
+
+def test_batch_host_api_ragged():
+    """m4g_find_matches_batch: host buffers, ragged chunk sizes incl. empty."""
+    sizes = [0, 5, 8, 70001, 1 << 16, 12345, 0, 200000]
+    blob = b"".join(synth.text(s, 40 + i) for i, s in enumerate(sizes))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    out, out_off, histos = m4.find_matches_batch(blob, off, (0,), True, **PARAMS_G)
+    for c, s in enumerate(sizes):
+        chunk = blob[int(off[c]):int(off[c + 1])]
+        ref = OracleM4(**PARAMS_G).FindMatches(chunk)
+        assert same(out[int(out_off[c]):int(out_off[c + 1])], ref), f"chunk {c}"
+        lit, cmd, dist, _, _ = histograms(chunk, ref)
+        assert (histos[c, :256] == lit).all() and (histos[c, 256:960] == cmd).all() \
+            and (histos[c, 960:] == dist).all()
+
+
+def test_full_size_chunks_properties():
+    """BASELINE config 2 shape (1 MiB chunks, params G): size-independent
+    properties on every chunk + bit-exactness on a sample."""
+    n, nchunks = 1 << 20, 64
+    host = np.empty(n * nchunks, dtype=np.uint8)
+    synth.fill(host, n, 0, "text", 8)
+    out, o, h = _run_batch(host, n, nchunks, PARAMS_G)
+    m = out[:o[-1]].astype(np.int64)
+    # every chunk's matches cover exactly n bytes
+    cover = np.add.reduceat(m[:, 0] + m[:, 1], o[:-1].astype(np.int64))
+    assert (cover == n).all()
+    # literal histogram total == sum of Unmatched; command total == match count
+    lit_tot = np.add.reduceat(m[:, 0], o[:-1].astype(np.int64))
+    assert (h[:, :256].sum(axis=1) == lit_tot).all()
+    assert (h[:, 256:960].sum(axis=1) == np.diff(o)).all()
+    for c in (0, 17, 63):
+        chunk = host[c * n:(c + 1) * n]
+        got = out[o[c]:o[c + 1]]
+        assert replay(got, chunk.tobytes()) == chunk.tobytes()
+        assert same(got, OracleM4(**PARAMS_G).FindMatches(chunk)), f"chunk {c}"
