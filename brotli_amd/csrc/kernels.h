@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "m4_parse.h"
+#include "m4_spec.h"
 
 namespace m4g {
 
@@ -21,11 +22,10 @@ namespace m4g {
 struct Job {
   uint64_t src_off;   // byte offset of buffer position 0 in the src base
   uint64_t chain_off; // element offset of position 0 in the chain base
-  uint64_t slot_off;  // first Rec of this job's output slot
   uint32_t start;     // first position to insert / parse (e.NextEmit at entry)
   uint32_t len;       // buffer length (positions [start, len-7) are inserted)
   uint32_t seed_prev; // Distance of the caller's last dst element, 0 = none
-  uint32_t slot_cap;  // Recs available in the slot
+  uint32_t pad;
 };
 
 constexpr uint64_t kHashMul64 = 0x1E35A7BD1E35A7BDull; // m4.go:285
@@ -129,39 +129,162 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
 }
 
 // ---------------------------------------------------------------------------
-// K3 (serial form): one lane walks one job from start to end.
+// K3: the parse, spread over lanes by sub-block speculation (m4_spec.h).
+//
+//   k3a_spec      one lane per (job, sub-block): speculative parse -> RS slot,
+//                 end state E.
+//   k3b_stitch    one lane per (job, sub-block >= 1): true parse from E[k-1]
+//                 until it synchronises with RS[k] -> ST slot, descriptor,
+//                 Tout (true state after the block when it did not sync).
+//   k3c_validate  one wave per job: walks the blocks in order; as long as every
+//                 block synchronised, the assumption "block k is entered in
+//                 state E[k-1]" holds by induction and only offsets are summed
+//                 (64 blocks per step).  After a block that did not sync, the
+//                 following blocks are re-stitched serially from the true
+//                 state until one synchronises again.
+// Slot layout: block b = job * kmax + k owns RS/ST records [b*slot, (b+1)*slot).
 // ---------------------------------------------------------------------------
-struct SlotSink {
-  Rec *out;
-  uint32_t n, cap;
-  __device__ __forceinline__ void push(const Rec &r) {
-    if (n < cap) {
-      uint4 v = make_uint4(r.unmatched, r.length, r.distance, r.lit_start);
-      *reinterpret_cast<uint4 *>(out + n) = v;
-    }
-    n++;
-  }
+struct SpecLayout {
+  uint32_t kmax;      // sub-blocks reserved per job
+  uint32_t slot;      // Recs per (job, block) slot in RS and in ST
+  int32_t sub_block;  // positions per sub-block
 };
 
-__global__ __launch_bounds__(64) void k3_parse_serial(
+constexpr int K3_THREADS = 64;
+
+__global__ __launch_bounds__(K3_THREADS) void k3a_spec(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
-    const Job *__restrict__ jobs, Rec *__restrict__ slots,
-    uint32_t *__restrict__ counts, uint32_t *__restrict__ errors, int njobs,
+    const Job *__restrict__ jobs, Rec *__restrict__ rs, ParseState *__restrict__ E,
+    BlockDesc *__restrict__ desc, uint32_t *__restrict__ errors, int njobs, SpecLayout L,
     ParseParams P) {
-  // one wave per job, lane 0 runs the state machine
-  const uint32_t job = blockIdx.x;
-  if (job >= (uint32_t)njobs || threadIdx.x != 0) return;
+  const uint64_t t = (uint64_t)blockIdx.x * K3_THREADS + threadIdx.x;
+  const uint32_t job = (uint32_t)(t / L.kmax), k = (uint32_t)(t % L.kmax);
+  if (job >= (uint32_t)njobs) return;
   const Job J = jobs[job];
+  const SpecGeom g = spec_geom(J.start, J.len, L.sub_block);
+  if (k >= (uint32_t)g.nblocks) return;
   const uint8_t *src = src_base + J.src_off;
   const uint32_t *chain = chain_base + J.chain_off;
-  SlotSink sink{slots + J.slot_off, 0, J.slot_cap};
+  RecSink sink{rs + t * L.slot, 0, L.slot};
   ParseState S;
-  state_init(S, (int32_t)J.start, J.seed_prev);
-  const int32_t len = (int32_t)J.len;
-  parse_range(src, len, chain, P, S, len - 7, sink);
-  parse_finish(len, P, S, sink);
-  counts[job] = sink.n;
+  spec_parse_block(src, (int32_t)J.len, chain, P, g, (int32_t)k, J.seed_prev, S, sink);
+  E[t] = S;
+  BlockDesc d;
+  d.n_spec = sink.n;
+  d.n_stitch = 0;
+  d.keep_from = 0;
+  d.out_off = 0;
+  desc[t] = d;
+  if (sink.n > L.slot) atomicOr(errors, 2u);
   if (S.error) atomicOr(errors, 1u);
+}
+
+// desc.out_off doubles as the "synchronised" flag between k3b and k3c.
+__global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
+    const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
+    const Job *__restrict__ jobs, const Rec *__restrict__ rs, Rec *__restrict__ st,
+    const ParseState *__restrict__ E, ParseState *__restrict__ Tout,
+    BlockDesc *__restrict__ desc, uint32_t *__restrict__ errors, int njobs, SpecLayout L,
+    ParseParams P) {
+  const uint64_t t = (uint64_t)blockIdx.x * K3_THREADS + threadIdx.x;
+  const uint32_t job = (uint32_t)(t / L.kmax), k = (uint32_t)(t % L.kmax);
+  if (job >= (uint32_t)njobs || k == 0) return;
+  const Job J = jobs[job];
+  const SpecGeom g = spec_geom(J.start, J.len, L.sub_block);
+  if (k >= (uint32_t)g.nblocks) return;
+  const uint8_t *src = src_base + J.src_off;
+  const uint32_t *chain = chain_base + J.chain_off;
+  RecSink sink{st + t * L.slot, 0, L.slot};
+  ParseState T = E[t - 1];
+  BlockDesc d = desc[t];
+  uint32_t keep = 0;
+  const bool ok = stitch_block(src, (int32_t)J.len, chain, P, g, (int32_t)k, rs + t * L.slot,
+                               min(d.n_spec, L.slot), E[t], T, sink, keep);
+  d.n_stitch = sink.n;
+  d.keep_from = keep;
+  d.out_off = ok ? 1u : 0u;
+  desc[t] = d;
+  if (!ok) Tout[t] = T;
+  if (sink.n > L.slot) atomicOr(errors, 2u);
+}
+
+__global__ __launch_bounds__(64) void k3c_validate(
+    const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
+    const Job *__restrict__ jobs, const Rec *__restrict__ rs, Rec *__restrict__ st,
+    const ParseState *__restrict__ E, const ParseState *__restrict__ Tout,
+    BlockDesc *__restrict__ desc, uint32_t *__restrict__ counts, uint32_t *__restrict__ errors,
+    int njobs, SpecLayout L, ParseParams P) {
+  const uint32_t job = blockIdx.x;
+  if (job >= (uint32_t)njobs) return;
+  const int lane = threadIdx.x;
+  const Job J = jobs[job];
+  const SpecGeom g = spec_geom(J.start, J.len, L.sub_block);
+  const uint32_t K = (uint32_t)g.nblocks;
+  const uint64_t b0 = (uint64_t)job * L.kmax;
+  const uint8_t *src = src_base + J.src_off;
+  const uint32_t *chain = chain_base + J.chain_off;
+
+  uint32_t off = desc[b0].n_spec; // block 0: the speculative parse IS the true parse
+  if (lane == 0) desc[b0].out_off = 0;
+  uint32_t k = 1;
+  bool valid = true;
+  ParseState T; // meaningful only while !valid
+  state_init(T, 0, 0);
+  uint32_t err = 0;
+  while (k < K) {
+    if (valid) {
+      const uint32_t kk = k + lane;
+      BlockDesc d{0, 0, 0, 1};
+      if (kk < K) d = desc[b0 + kk];
+      const unsigned long long bad = __ballot(kk < K && d.out_off == 0);
+      const uint32_t room = min(64u, K - k);
+      const uint32_t ngood = bad ? min((uint32_t)__builtin_ctzll(bad), room) : room;
+      uint32_t cnt = (uint32_t)lane < ngood ? d.n_stitch + (d.n_spec - d.keep_from) : 0;
+      uint32_t incl = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if ((uint32_t)lane < ngood) desc[b0 + kk].out_off = off + incl - cnt;
+      off += __shfl(incl, 63);
+      k += ngood;
+      if (bad && k < K) {
+        // block k did not synchronise, but it was entered in the right state:
+        // its stitch records are the true records of the whole block.
+        const int bl = (int)ngood;
+        const uint32_t ns = __shfl(d.n_stitch, bl);
+        if (lane == bl) desc[b0 + k].out_off = off;
+        off += ns;
+        T = Tout[b0 + k];
+        valid = false;
+        k++;
+      }
+    } else {
+      // serial re-stitch of block k from the true state (uniform over lanes)
+      const uint64_t t = b0 + k;
+      RecSink sink{st + t * L.slot, 0, L.slot};
+      const BlockDesc d = desc[t];
+      uint32_t keep = 0;
+      const bool ok = stitch_block(src, (int32_t)J.len, chain, P, g, (int32_t)k, rs + t * L.slot,
+                                   min(d.n_spec, L.slot), E[t], T, sink, keep);
+      if (sink.n > L.slot) err |= 2u;
+      if (lane == 0) {
+        BlockDesc nd = d;
+        nd.n_stitch = sink.n;
+        nd.keep_from = keep;
+        nd.out_off = off;
+        desc[t] = nd;
+      }
+      off += sink.n + (d.n_spec - keep);
+      if (ok) valid = true;
+      k++;
+    }
+  }
+  if (!valid && T.error) err |= 1u;
+  if (lane == 0) {
+    counts[job] = off;
+    if (err) atomicOr(errors, err);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -194,35 +317,45 @@ __global__ __launch_bounds__(1024) void k4_scan_counts(
   if (tid == 0) out_off[njobs] = carry_s;
 }
 
-// grid = (njobs, K4_SPLIT): each workgroup copies a strided share of one slot.
-constexpr int K4_SPLIT = 4;
-__global__ __launch_bounds__(256) void k4_compact(
-    const Rec *__restrict__ slots, const Job *__restrict__ jobs,
-    const uint32_t *__restrict__ counts, const uint64_t *__restrict__ out_off,
-    uint32_t *__restrict__ out /* 3 words per match */, uint64_t out_cap) {
-  const uint32_t job = blockIdx.x;
+// One wave per (job, sub-block): copy the block's true records (stitch part,
+// then the kept speculative part) to their place in the job's Match list.
+constexpr int K4_THREADS = 256;
+__global__ __launch_bounds__(K4_THREADS) void k4_compact(
+    const Rec *__restrict__ rs, const Rec *__restrict__ st, const Job *__restrict__ jobs,
+    const BlockDesc *__restrict__ desc, const uint64_t *__restrict__ out_off,
+    uint32_t *__restrict__ out /* 3 words per match */, uint64_t out_cap, int njobs, SpecLayout L) {
+  const uint64_t t = (uint64_t)blockIdx.x * (K4_THREADS / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const uint32_t job = (uint32_t)(t / L.kmax), k = (uint32_t)(t % L.kmax);
+  if (job >= (uint32_t)njobs) return;
   const Job J = jobs[job];
-  const uint32_t n = min(counts[job], J.slot_cap);
-  const uint64_t o = out_off[job];
-  const Rec *s = slots + J.slot_off;
-  for (uint32_t k = blockIdx.y * blockDim.x + threadIdx.x; k < n; k += blockDim.x * K4_SPLIT) {
-    if (o + k >= out_cap) break;
-    uint4 v = *reinterpret_cast<const uint4 *>(s + k);
-    uint32_t *d = out + (o + k) * 3;
-    d[0] = v.x;
-    d[1] = v.y;
-    d[2] = v.z;
+  const SpecGeom g = spec_geom(J.start, J.len, L.sub_block);
+  if (k >= (uint32_t)g.nblocks) return;
+  const BlockDesc d = desc[t];
+  const uint64_t o = out_off[job] + d.out_off;
+  const uint32_t ns = min(d.n_stitch, L.slot);
+  const uint32_t nk = min(d.n_spec, L.slot) - min(d.keep_from, min(d.n_spec, L.slot));
+  const Rec *a = st + t * L.slot;
+  const Rec *b = rs + t * L.slot + d.keep_from;
+  for (uint32_t r = lane; r < ns + nk; r += 64) {
+    if (o + r >= out_cap) break;
+    const uint4 v = *reinterpret_cast<const uint4 *>(r < ns ? a + r : b + (r - ns));
+    uint32_t *dst = out + (o + r) * 3;
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
   }
 }
 
 // ---------------------------------------------------------------------------
-// K5: histograms (encoder.go:44-105).
+// K5: histograms (encoder.go:44-105) over the compacted Match list of a job.
 //
-// The only sequential piece of that pass is the ring of the last four
-// distances.  A distance is pushed exactly when it differs from the previous
-// match's distance, so the ring seen by match j is the
-// last four "flagged" matches before j.  A max-scan gives every match the
-// index of the latest flagged match before it (stored in pf[]); four hops
+// The only sequential pieces of that pass are (a) the running input position
+// (sum of Unmatched+Length) and (b) the ring of the last four distances.
+// (a) is a prefix sum.  (b): a distance is pushed exactly when it differs from
+// the previous match's distance, so the ring seen by
+// match j is the last four "flagged" matches before j; a max-scan gives every
+// match the index of the latest flagged match before it (pf[]), and four hops
 // along pf[] rebuild the ring with no serial dependence between matches.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t log2_floor_nz(uint32_t n) { return 31u - __builtin_clz(n); }
@@ -270,22 +403,28 @@ constexpr int K5_THREADS = 256;
 constexpr int K5_WAVES = K5_THREADS / 64;
 
 __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
-    const uint8_t *__restrict__ src_base, const Rec *__restrict__ slots,
-    const Job *__restrict__ jobs, const uint32_t *__restrict__ counts,
+    const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ matches /* 3 words each */,
+    const Job *__restrict__ jobs, const uint64_t *__restrict__ out_off, uint64_t out_cap,
     uint32_t *__restrict__ pf_base, uint32_t *__restrict__ histos /* 1024 u32 per job */) {
   __shared__ uint32_t lit[K5_WAVES][256];
   __shared__ uint32_t cmd[704];
   __shared__ uint32_t dst[64];
-  __shared__ uint32_t wmax[K5_WAVES];
+  __shared__ uint32_t wred[K5_WAVES];
   __shared__ uint32_t carry_s;
 
   const uint32_t job = blockIdx.x;
   const Job J = jobs[job];
-  const uint32_t n = min(counts[job], J.slot_cap);
-  const Rec *rec = slots + J.slot_off;
-  uint32_t *pf = pf_base + J.slot_off;
-  const uint8_t *src = src_base + J.src_off + 0;
+  const uint64_t o0 = out_off[job], o1 = out_off[job + 1];
+  uint32_t *h = histos + (size_t)job * 1024;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (o1 > out_cap) { // list truncated by the caller's out_cap: no histogram
+    for (int k = tid; k < 1024; k += K5_THREADS) h[k] = 0;
+    return;
+  }
+  const uint32_t n = (uint32_t)(o1 - o0);
+  const uint32_t *rec = matches + o0 * 3;
+  uint32_t *pf = pf_base + o0;
+  const uint8_t *src = src_base + J.src_off;
 
   for (int k = tid; k < K5_WAVES * 256; k += K5_THREADS) (&lit[0][0])[k] = 0;
   for (int k = tid; k < 704; k += K5_THREADS) cmd[k] = 0;
@@ -297,22 +436,19 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
   for (uint32_t base = 0; base < n; base += K5_THREADS) {
     const uint32_t j = base + tid;
     uint32_t flag = 0;
-    if (j < n) {
-      uint4 v = *reinterpret_cast<const uint4 *>(rec + j);
-      if (v.y != 0) {
-        uint32_t prevd = j ? rec[j - 1].distance : 0xFFFFFFFFu;
-        flag = (v.z != prevd) ? j + 1 : 0;
-      }
+    if (j < n && rec[3 * j + 1] != 0) {
+      uint32_t prevd = j ? rec[3 * j - 1] : 0xFFFFFFFFu;
+      flag = (rec[3 * j + 2] != prevd) ? j + 1 : 0;
     }
     uint32_t incl = flag;
     for (int o = 1; o < 64; o <<= 1) {
       uint32_t t = __shfl_up(incl, o);
       if (lane >= o) incl = max(incl, t);
     }
-    if (lane == 63) wmax[wid] = incl;
+    if (lane == 63) wred[wid] = incl;
     __syncthreads();
     uint32_t before = carry_s;
-    for (int w = 0; w < wid; w++) before = max(before, wmax[w]);
+    for (int w = 0; w < wid; w++) before = max(before, wred[w]);
     uint32_t excl = __shfl_up(incl, 1);
     if (lane == 0) excl = 0;
     excl = max(excl, before);
@@ -321,22 +457,37 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
     if (tid == K5_THREADS - 1) carry_s = max(before, incl);
     __syncthreads();
   }
-  __threadfence_block();
+  if (tid == 0) carry_s = J.start; // pass 2 carry: input position of the next match
   __syncthreads();
 
-  // pass 2: command + distance symbols, literal histogram
+  // pass 2: positions, command + distance symbols, literal histogram
   uint32_t *mylit = lit[wid];
   for (uint32_t base = 0; base < n; base += K5_THREADS) {
     const uint32_t j = base + tid;
-    uint32_t un = 0, ls = 0;
+    uint32_t un = 0, len = 0, dist = 0;
     if (j < n) {
-      uint4 v = *reinterpret_cast<const uint4 *>(rec + j);
-      un = v.x;
-      ls = v.w;
-      const uint32_t len = v.y, dist = v.z;
+      un = rec[3 * j];
+      len = rec[3 * j + 1];
+      dist = rec[3 * j + 2];
+    }
+    // exclusive prefix sum of (un + len) = where this match's literals start
+    uint32_t adv = un + len, incl = adv;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wred[wid] = incl;
+    __syncthreads();
+    uint32_t before = carry_s;
+    for (int w = 0; w < wid; w++) before += wred[w];
+    const uint32_t ls = before + incl - adv;
+    __syncthreads();
+    if (tid == K5_THREADS - 1) carry_s = before + incl;
+
+    if (j < n) {
       uint32_t ic = insert_length_code(un);
       uint32_t cc = len ? copy_length_code(len) : 2u;
-      bool use_last = j > 0 && dist == rec[j - 1].distance;
+      bool use_last = j > 0 && dist == rec[3 * j - 1];
       uint32_t command = combine_length_codes(ic, cc, use_last);
       atomicAdd(&cmd[command], 1u);
       if (command >= 128 && len != 0) {
@@ -345,7 +496,7 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
         uint32_t p = pf[j];
         for (int t = 0; t < 4; t++) {
           if (p) {
-            ring[t] = (int64_t)rec[p - 1].distance;
+            ring[t] = (int64_t)rec[3 * (p - 1) + 2];
             p = pf[p - 1];
           } else {
             ring[t] = -10;
@@ -378,10 +529,10 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
       uint32_t u = __shfl(un, l), s0 = __shfl(ls, l);
       for (uint32_t k = lane; k < u; k += 64) atomicAdd(&mylit[src[s0 + k]], 1u);
     }
+    __syncthreads();
   }
   __syncthreads();
 
-  uint32_t *h = histos + (size_t)job * 1024;
   for (int k = tid; k < 256; k += K5_THREADS) {
     uint32_t s = 0;
     for (int w = 0; w < K5_WAVES; w++) s += lit[w][k];

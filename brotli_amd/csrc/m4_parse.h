@@ -105,13 +105,19 @@ M4G_HD AbsMatch extend2(const uint8_t *src, int32_t len, int32_t start,
 }
 
 // matchEmitter.emit (emitter.go:27-34) into a caller-provided sink.
+// Bit 31 of Rec.lit_start marks a record emitted as the newest pending match
+// by a loop-top flush (m4.go:124): right after it the machine state is fully
+// determined by (record end, record distance) -- a synchronisation point for
+// the speculative sub-block parse (m4_spec.h).
+constexpr uint32_t kRecFlushBit = 0x80000000u;
+
 template <class Sink>
-M4G_HD void emit(ParseState &S, const AbsMatch &m, Sink &sink) {
+M4G_HD void emit(ParseState &S, const AbsMatch &m, Sink &sink, uint32_t flag = 0) {
   Rec r;
   r.unmatched = (uint32_t)(m.start - S.next_emit);
   r.length = (uint32_t)(m.end - m.start);
   r.distance = (uint32_t)(m.start - m.match);
-  r.lit_start = (uint32_t)S.next_emit;
+  r.lit_start = (uint32_t)S.next_emit | flag;
   sink.push(r);
   S.next_emit = m.end;
   S.prev_dist = r.distance;
@@ -126,7 +132,7 @@ M4G_HD void flush(ParseState &S, const ParseParams &P, Sink &sink) {
     if (S.m1.end - S.m1.start >= P.min_length && score(S.m1, P.distance_bit_cost) > 0)
       emit(S, S.m1, sink);
   }
-  emit(S, S.m0, sink);
+  emit(S, S.m0, sink, kRecFlushBit);
   S.m0 = AbsMatch{0, 0, 0};
   S.m1 = AbsMatch{0, 0, 0};
 }
@@ -144,14 +150,23 @@ M4G_HD void state_init(ParseState &S, int32_t start, uint32_t seed_prev_distance
 // Runs loop iterations of m4.go:112-260 while S.i < stop (stop <= len-7).
 // `src`/`chain` are indexed by buffer position; `len` is the buffer length
 // (forward extension may read up to len, never past it).
-template <class Sink>
-M4G_HD void parse_range(const uint8_t *__restrict__ src, int32_t len,
+// With STOP_AT_FLUSH the function returns true right after a loop-top flush
+// (state saved at that position, before the repeat probe); it returns false
+// when the range is exhausted.
+template <bool STOP_AT_FLUSH = false, class Sink>
+M4G_HD bool parse_range(const uint8_t *__restrict__ src, int32_t len,
                         const uint32_t *__restrict__ chain, const ParseParams &P,
                         ParseState &S, int32_t stop, Sink &sink) {
   int32_t i = S.i;
   while (i < stop) {
     // A. m4.go:113-126
-    if (S.m0.end != 0 && i >= S.m0.end) flush(S, P, sink);
+    if (S.m0.end != 0 && i >= S.m0.end) {
+      flush(S, P, sink);
+      if (STOP_AT_FLUSH) {
+        S.i = i;
+        return true;
+      }
+    }
 
     // B. m4.go:128-138 repeat match one byte after the current position
     if (S.m0.end == 0 && S.have_prev) {
@@ -270,6 +285,7 @@ M4G_HD void parse_range(const uint8_t *__restrict__ src, int32_t len,
     i++;
   }
   S.i = i;
+  return false;
 }
 
 // m4.go:262-281: after the loop, emit what is pending plus the trailing

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -91,9 +92,61 @@ int k1_prepare() {
   return M4G_OK;
 }
 
+// Device buffers of the speculative parse (kernels.h, K3) for up to `blocks`
+// (job, sub-block) pairs.
+struct SpecWork {
+  SpecLayout L{};
+  size_t blocks = 0;
+  Rec *rs = nullptr, *st = nullptr;
+  ParseState *E = nullptr, *Tout = nullptr;
+  BlockDesc *desc = nullptr;
+};
+
+void spec_free(SpecWork &w) {
+  (void)hipFree(w.rs);
+  (void)hipFree(w.st);
+  (void)hipFree(w.E);
+  (void)hipFree(w.Tout);
+  (void)hipFree(w.desc);
+  w = SpecWork{};
+}
+
+constexpr int kDefaultSubBlock = 1024;
+
+int sub_block_size() {
+  const char *e = std::getenv("M4G_SUB_BLOCK");
+  int v = e ? std::atoi(e) : kDefaultSubBlock;
+  return v >= 64 && v <= (1 << 24) ? v : kDefaultSubBlock;
+}
+
+// Layout for jobs of at most max_bytes buffer positions to parse.
+int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes) {
+  spec_free(w);
+  w.L.sub_block = sub_block_size();
+  w.L.kmax = (uint32_t)std::max<size_t>(1, (max_bytes + (size_t)w.L.sub_block - 1) / (size_t)w.L.sub_block);
+  // records a parse can emit while walking one sub-block: the matches are
+  // disjoint and at least min_length long, plus the pending ones at entry and
+  // the tail records of the last block.
+  w.L.slot = (uint32_t)((size_t)w.L.sub_block / (size_t)p.min_length + 18);
+  w.blocks = max_jobs * w.L.kmax;
+  const size_t nrec = w.blocks * w.L.slot;
+  if (hipMalloc(&w.rs, nrec * sizeof(Rec)) != hipSuccess ||
+      hipMalloc(&w.st, nrec * sizeof(Rec)) != hipSuccess ||
+      hipMalloc(&w.E, w.blocks * sizeof(ParseState)) != hipSuccess ||
+      hipMalloc(&w.Tout, w.blocks * sizeof(ParseState)) != hipSuccess ||
+      hipMalloc(&w.desc, w.blocks * sizeof(BlockDesc)) != hipSuccess) {
+    (void)hipGetLastError();
+    spec_free(w);
+    return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the parse workspace failed");
+  }
+  return M4G_OK;
+}
+
 // Launches K1 + K3 for `njobs` jobs whose descriptors are already in d_jobs.
+// On return (stream order) counts[job] holds the job's match count and the
+// records sit in w.rs / w.st as described by w.desc.
 int launch_find(const Params &p, const uint8_t *d_src, uint32_t *d_chain, const Job *d_jobs,
-                uint32_t *d_table_io, int njobs, Rec *d_slots, uint32_t *d_counts,
+                uint32_t *d_table_io, int njobs, const SpecWork &w, uint32_t *d_counts,
                 uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
   const int pb = part_bits_of(p);
   const int nparts = 1 << (p.table_bits - pb);
@@ -103,8 +156,32 @@ int launch_find(const Params &p, const uint8_t *d_src, uint32_t *d_chain, const 
                      d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb);
   HIP_TRY(hipGetLastError());
   if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st));
-  hipLaunchKernelGGL(k3_parse_serial, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain,
-                     d_jobs, d_slots, d_counts, d_errors, njobs, parse_params(p));
+  const ParseParams P = parse_params(p);
+  const uint64_t lanes = (uint64_t)njobs * w.L.kmax;
+  const unsigned g3 = (unsigned)((lanes + K3_THREADS - 1) / K3_THREADS);
+  hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs, w.E,
+                     w.desc, d_errors, njobs, w.L, P);
+  HIP_TRY(hipGetLastError());
+  if (w.L.kmax > 1) {
+    hipLaunchKernelGGL(k3b_stitch, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
+                       w.st, w.E, w.Tout, w.desc, d_errors, njobs, w.L, P);
+    HIP_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k3c_validate, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain, d_jobs,
+                     w.rs, w.st, w.E, w.Tout, w.desc, d_counts, d_errors, njobs, w.L, P);
+  HIP_TRY(hipGetLastError());
+  return M4G_OK;
+}
+
+// K4 for jobs already through launch_find: offsets, then the records.
+int launch_compact(const SpecWork &w, const Job *d_jobs, const uint32_t *d_counts, int njobs,
+                   uint64_t *d_out_off, m4g_match *d_out, size_t out_cap, hipStream_t st) {
+  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, d_counts, d_out_off, njobs);
+  HIP_TRY(hipGetLastError());
+  const uint64_t waves = (uint64_t)njobs * w.L.kmax;
+  const unsigned g4 = (unsigned)((waves + (K4_THREADS / 64) - 1) / (K4_THREADS / 64));
+  hipLaunchKernelGGL(k4_compact, dim3(g4), dim3(K4_THREADS), 0, st, w.rs, w.st, d_jobs, w.desc,
+                     d_out_off, reinterpret_cast<uint32_t *>(d_out), (uint64_t)out_cap, njobs, w.L);
   HIP_TRY(hipGetLastError());
   return M4G_OK;
 }
@@ -156,9 +233,9 @@ extern "C" void m4g_host_free(void *p) {
 struct m4g_batch {
   int device = 0;
   Params p{};
-  size_t max_chunks = 0, max_chunk_bytes = 0, slot_cap = 0;
+  size_t max_chunks = 0, max_chunk_bytes = 0, pf_cap = 0;
   uint32_t *d_chain = nullptr;
-  Rec *d_slots = nullptr;
+  SpecWork w;
   uint32_t *d_pf = nullptr;
   uint32_t *d_counts = nullptr;
   uint32_t *d_errors = nullptr;
@@ -173,7 +250,7 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   (void)hipFree(b->d_chain);
-  (void)hipFree(b->d_slots);
+  spec_free(b->w);
   (void)hipFree(b->d_pf);
   (void)hipFree(b->d_counts);
   (void)hipFree(b->d_errors);
@@ -203,13 +280,15 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   b->p = p;
   b->max_chunks = max_chunks;
   b->max_chunk_bytes = max_chunk_bytes;
-  b->slot_cap = max_chunk_bytes / (size_t)p.min_length + 2;
+  b->pf_cap = max_chunks * (max_chunk_bytes / (size_t)p.min_length + 2);
   const size_t nbytes = max_chunks * max_chunk_bytes;
-  const size_t nrec = max_chunks * b->slot_cap;
+  if ((rc = spec_alloc(b->w, p, max_chunks, max_chunk_bytes))) {
+    m4g_batch_destroy(b);
+    return rc;
+  }
   hipError_t e;
   if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 64)) != hipSuccess ||
-      (e = hipMalloc(&b->d_slots, nrec * sizeof(Rec))) != hipSuccess ||
-      (e = hipMalloc(&b->d_pf, nrec * 4)) != hipSuccess ||
+      (e = hipMalloc(&b->d_pf, b->pf_cap * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_counts, max_chunks * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_errors, 64)) != hipSuccess ||
       (e = hipMalloc(&b->d_jobs, max_chunks * sizeof(Job))) != hipSuccess) {
@@ -262,11 +341,10 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
       Job &J = jobs[c];
       J.src_off = chunk_off[c];
       J.chain_off = chain_off;
-      J.slot_off = (uint64_t)c * b->slot_cap;
       J.start = 0;
       J.len = (uint32_t)n;
       J.seed_prev = 0;
-      J.slot_cap = (uint32_t)b->slot_cap;
+      J.pad = 0;
       chain_off += (n + 15) & ~(uint64_t)15;
     }
     // pageable source: the runtime stages it before returning, so `jobs` may die.
@@ -276,23 +354,19 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
 
   HIP_TRY(hipMemsetAsync(b->d_errors, 0, 4, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  int rc = launch_find(b->p, d_src, b->d_chain, b->d_jobs, nullptr, njobs, b->d_slots, b->d_counts,
+  int rc = launch_find(b->p, d_src, b->d_chain, b->d_jobs, nullptr, njobs, b->w, b->d_counts,
                        b->d_errors, st, b->timing ? b->ev[1] : nullptr);
   if (rc) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
-
-  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, b->d_counts, d_out_off, njobs);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k4_compact, dim3((unsigned)njobs, K4_SPLIT), dim3(256), 0, st, b->d_slots,
-                     b->d_jobs, b->d_counts, d_out_off, reinterpret_cast<uint32_t *>(d_out),
-                     (uint64_t)out_cap);
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_compact(b->w, b->d_jobs, b->d_counts, njobs, d_out_off, d_out, out_cap, st)))
+    return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
 
   if (d_histos) {
     static_assert(sizeof(m4g_histo) == 1024 * 4, "m4g_histo layout");
     hipLaunchKernelGGL(k5_histograms, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
-                       b->d_slots, b->d_jobs, b->d_counts, b->d_pf,
+                       reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
+                       (uint64_t)std::min(out_cap, b->pf_cap), b->d_pf,
                        reinterpret_cast<uint32_t *>(d_histos));
     HIP_TRY(hipGetLastError());
   }
@@ -434,7 +508,8 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
     BATCH_TRY(hipMemcpy(&err, P.plan->d_errors, 4, hipMemcpyDeviceToHost));
     if (err) {
       cleanup();
-      return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+      return err & 2u ? fail(M4G_ERR_HIP, "internal: parse slot overflow")
+                      : fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
     }
   }
   uint64_t run = 0;
@@ -506,12 +581,15 @@ struct m4g_ctx {
   size_t cap = 0;      // capacity (bytes / chain entries)
   int64_t hist_len = 0;
   uint32_t *d_table = nullptr;
-  Rec *d_slots = nullptr;
-  size_t slot_cap = 0;
+  SpecWork w;
+  size_t w_bytes = 0;           // block size the parse workspace was sized for
+  m4g_match *d_out = nullptr;   // compacted matches of the last block
+  uint64_t *d_out_off = nullptr;
+  size_t out_cap = 0;
   uint32_t *d_counts = nullptr; // [0] count, [1] errors
   Job *d_job = nullptr;
-  Rec *h_recs = nullptr; // pinned staging
-  size_t h_recs_cap = 0;
+  m4g_match *h_recs = nullptr; // pinned staging
+  uint64_t *h_off = nullptr;   // pinned, 2 words
   uint32_t *h_counts = nullptr; // pinned, 2 words
 };
 
@@ -522,10 +600,13 @@ extern "C" void m4g_destroy(m4g_ctx *c) {
   (void)hipFree(c->d_hist);
   (void)hipFree(c->d_chain);
   (void)hipFree(c->d_table);
-  (void)hipFree(c->d_slots);
+  spec_free(c->w);
+  (void)hipFree(c->d_out);
+  (void)hipFree(c->d_out_off);
   (void)hipFree(c->d_counts);
   (void)hipFree(c->d_job);
   if (c->h_recs) (void)hipHostFree(c->h_recs);
+  if (c->h_off) (void)hipHostFree(c->h_off);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
@@ -548,6 +629,8 @@ extern "C" int m4g_create(const m4g_params *params, int device, m4g_ctx **out) {
       hipMalloc(&c->d_table, tbytes) != hipSuccess || hipMalloc(&c->d_counts, 64) != hipSuccess ||
       hipMalloc(&c->d_job, sizeof(Job)) != hipSuccess ||
       hipHostMalloc(&c->h_counts, 64, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(&c->h_off, 64, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(&c->d_out_off, 64) != hipSuccess ||
       hipMemsetAsync(c->d_table, 0, tbytes, c->st) != hipSuccess) {
     m4g_destroy(c);
     return fail(M4G_ERR_NO_MEMORY, "allocating the streaming handle failed");
@@ -625,16 +708,21 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
 
   int rc = ctx_reserve(c, (size_t)c->hist_len + n);
   if (rc) return rc;
-  if (c->slot_cap < need) {
-    (void)hipFree(c->d_slots);
-    c->d_slots = nullptr;
+  if (c->w_bytes < n) {
+    size_t nb = std::max(n, (size_t)1 << 16);
+    if ((rc = spec_alloc(c->w, p, 1, nb))) return rc;
+    c->w_bytes = nb;
+  }
+  if (c->out_cap < need) {
+    (void)hipFree(c->d_out);
+    c->d_out = nullptr;
     if (c->h_recs) (void)hipHostFree(c->h_recs);
     c->h_recs = nullptr;
     size_t nc = std::max(need, (size_t)4096);
-    if (hipMalloc(&c->d_slots, nc * sizeof(Rec)) != hipSuccess ||
-        hipHostMalloc(&c->h_recs, nc * sizeof(Rec), hipHostMallocDefault) != hipSuccess)
-      return fail(M4G_ERR_NO_MEMORY, "allocating the match slot failed");
-    c->slot_cap = nc;
+    if (hipMalloc(&c->d_out, nc * sizeof(m4g_match)) != hipSuccess ||
+        hipHostMalloc(&c->h_recs, nc * sizeof(m4g_match), hipHostMallocDefault) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "allocating the match buffers failed");
+    c->out_cap = nc;
   }
 
   // m4.go:101-107: append src
@@ -642,33 +730,30 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   Job J{};
   J.src_off = 0;
   J.chain_off = 0;
-  J.slot_off = 0;
   J.start = (uint32_t)c->hist_len;
   J.len = (uint32_t)(c->hist_len + (int64_t)n);
   J.seed_prev = seed_prev_distance;
-  J.slot_cap = (uint32_t)c->slot_cap;
   HIP_TRY(hipMemcpyAsync(c->d_job, &J, sizeof(Job), hipMemcpyHostToDevice, c->st));
   HIP_TRY(hipMemsetAsync(c->d_counts, 0, 8, c->st));
   // positions in [start, len-7) that K1 does not visit keep chain = 0 only if
   // cleared: the last 7 of every block are never inserted (m4.go:112).
   HIP_TRY(hipMemsetAsync(c->d_chain + c->hist_len, 0, n * 4, c->st));
-  rc = launch_find(p, c->d_hist, c->d_chain, c->d_job, c->d_table, 1, c->d_slots, c->d_counts,
+  rc = launch_find(p, c->d_hist, c->d_chain, c->d_job, c->d_table, 1, c->w, c->d_counts,
                    c->d_counts + 1, c->st, nullptr);
   if (rc) return rc;
+  if ((rc = launch_compact(c->w, c->d_job, c->d_counts, 1, c->d_out_off, c->d_out, c->out_cap, c->st)))
+    return rc;
   HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
   c->hist_len += (int64_t)n;
-  if (c->h_counts[1]) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+  if (c->h_counts[1] & 1u) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+  if (c->h_counts[1] & 2u) return fail(M4G_ERR_HIP, "internal: parse slot overflow");
   const uint32_t cnt = c->h_counts[0];
-  if (cnt > c->slot_cap) return fail(M4G_ERR_HIP, "internal: match slot overflow");
+  if (cnt > c->out_cap || cnt > out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
   if (cnt) {
-    HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_slots, (size_t)cnt * sizeof(Rec), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_out, (size_t)cnt * sizeof(m4g_match), hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
-    for (uint32_t k = 0; k < cnt; k++) {
-      out[k].unmatched = c->h_recs[k].unmatched;
-      out[k].length = c->h_recs[k].length;
-      out[k].distance = c->h_recs[k].distance;
-    }
+    std::memcpy(out, c->h_recs, (size_t)cnt * sizeof(m4g_match));
   }
   return (int64_t)cnt;
 }

@@ -52,15 +52,17 @@ int64_t sim_find_matches(const uint8_t *src, int32_t n, int max_distance, int mi
   parse_range(src, n, chain.data(), P, S, n - 7, sink);
   parse_finish(n, P, S, sink);
   if ((int64_t)sink.v.size() > out_cap) return -(int64_t)sink.v.size();
+  for (auto &r : sink.v) r.lit_start &= ~kRecFlushBit;
   if (!sink.v.empty()) std::memcpy(out, sink.v.data(), sink.v.size() * sizeof(Rec));
   return S.error ? INT64_MIN : (int64_t)sink.v.size();
 }
 
 #ifdef HAVE_SPEC
 // Same result through the speculative sub-block scheme of m4_spec.h, executed
-// sequentially on the host exactly as kernels K3a/K3b do on the device.
+// sequentially on the host in the order the device kernels use (all phase-A
+// blocks first, then phase B in block order).
 // stats[0] = sub-blocks, stats[1] = sub-blocks that synchronised,
-// stats[2] = positions re-parsed by the stitcher.
+// stats[2] = positions walked by the stitcher, stats[3] = stitch records.
 int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, int min_length,
                               int hash_len, int table_bits, int chain_length,
                               int distance_bit_cost, uint32_t seed_prev, int32_t sub_block,
@@ -68,12 +70,45 @@ int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, i
   ParseParams P{max_distance, min_length, hash_len, chain_length, distance_bit_cost};
   std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
   build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
-  std::vector<Rec> result;
-  uint32_t err = 0;
-  spec_host_run(src, n, chain.data(), P, 0, seed_prev, sub_block, result, stats, &err);
+  const SpecGeom g = spec_geom(0, (uint32_t)n, sub_block);
+  const int K = g.nblocks;
+  std::vector<std::vector<Rec>> RS(K);
+  std::vector<ParseState> E(K);
+  for (int k = 0; k < K; k++) {
+    VecSink sink;
+    spec_parse_block(src, n, chain.data(), P, g, k, seed_prev, E[k], sink);
+    RS[k] = std::move(sink.v);
+  }
+  std::vector<Rec> result = RS[0];
+  ParseState T = E[0];
+  int64_t synced = 0, walked = 0, nst = 0;
+  for (int k = 1; k < K; k++) {
+    VecSink st;
+    uint32_t keep = 0;
+    int32_t i0 = T.i;
+    bool ok = stitch_block(src, n, chain.data(), P, g, k, RS[k].data(), (uint32_t)RS[k].size(),
+                           E[k], T, st, keep);
+    synced += ok;
+    if (ok) {
+      int32_t e = rec_end(st.v.back());
+      walked += e > i0 ? e - i0 : 0;
+    } else {
+      walked += block_end(g, k) > i0 ? block_end(g, k) - i0 : 0;
+    }
+    nst += (int64_t)st.v.size();
+    result.insert(result.end(), st.v.begin(), st.v.end());
+    result.insert(result.end(), RS[k].begin() + keep, RS[k].end());
+  }
+  if (stats) {
+    stats[0] = K;
+    stats[1] = synced;
+    stats[2] = walked;
+    stats[3] = nst;
+  }
+  for (auto &r : result) r.lit_start &= ~kRecFlushBit;
   if ((int64_t)result.size() > out_cap) return -(int64_t)result.size();
   if (!result.empty()) std::memcpy(out, result.data(), result.size() * sizeof(Rec));
-  return err ? INT64_MIN : (int64_t)result.size();
+  return T.error ? INT64_MIN : (int64_t)result.size();
 }
 #endif
 }

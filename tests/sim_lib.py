@@ -1,0 +1,49 @@
+"""ctypes access to tests/sim/libparse_sim.so (host build of the parse header;
+test harness only)."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        L = ctypes.CDLL(os.path.join(_HERE, "sim", "libparse_sim.so"))
+        L.sim_find_matches.restype = ctypes.c_int64
+        L.sim_find_matches.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_int] * 6 + \
+            [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]
+        L.sim_find_matches_spec.restype = ctypes.c_int64
+        L.sim_find_matches_spec.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_int] * 6 + \
+            [ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        _L = L
+    return _L
+
+
+def _args(data, MaxDistance=0, MinLength=0, HashLen=0, TableBits=0, ChainLength=0,
+          DistanceBitCost=0):
+    a = np.frombuffer(bytes(data), dtype=np.uint8)
+    buf = np.concatenate([a, np.zeros(16, np.uint8)])
+    out = np.zeros((len(a) // (MinLength or 4) + 8, 4), dtype=np.uint32)
+    p = (MaxDistance or 65535, MinLength or 4, HashLen or 6, TableBits or 17, ChainLength,
+         DistanceBitCost)
+    return a, buf, out, p
+
+
+def sim(data, seed=0, **kw):
+    a, buf, out, p = _args(data, **kw)
+    r = lib().sim_find_matches(buf.ctypes.data, len(a), *p, seed, out.ctypes.data, len(out))
+    assert r >= 0, r
+    return out[:r, :3].copy()
+
+
+def sim_spec(data, sub_block, seed=0, **kw):
+    a, buf, out, p = _args(data, **kw)
+    stats = np.zeros(4, dtype=np.int64)
+    r = lib().sim_find_matches_spec(buf.ctypes.data, len(a), *p, seed, sub_block,
+                                    out.ctypes.data, len(out), stats.ctypes.data)
+    assert r >= 0, r
+    return out[:r, :3].copy(), stats
