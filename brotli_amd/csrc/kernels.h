@@ -42,27 +42,168 @@ constexpr uint64_t kHashMul64 = 0x1E35A7BD1E35A7BDull; // m4.go:285
 //     LDS); one workgroup owns one (job, partition) and streams the whole
 //     buffer region, so the 4 partition workgroups of a job are placed on one
 //     XCD (blockIdx % 8 equal) and share its L2 for the input bytes;
-//   * positions are processed in tiles of blockDim.x in increasing order;
-//     inside a tile  old = table[h]  ->  barrier  ->  ds_max(table[h], i)  ->
-//     barrier  ->  a position that does not read itself back has a later
-//     duplicate in the same tile; those rare "losers" go to a short LDS list
-//     that same-hash positions scan to find an in-tile predecessor.
+//   * the input is staged through LDS in tiles of K1_SUB positions with
+//     coalesced 16-byte loads (the next tile is in flight while the current
+//     one is processed); every thread forms its unaligned 8-byte hash windows
+//     from LDS;
+//   * every wave hashes 64*K1_PER positions and compacts the ~1/nparts of
+//     them that fall into this partition into a per-wave LDS queue (ballot +
+//     mbcnt, position order is kept), so the table protocol below runs on
+//     dense lanes;
+//   * consecutive queue entries with equal hash and consecutive positions
+//     ("runs", e.g. zero pages) are folded: the run head stands for the run
+//     and carries its last position, interior positions have chain = 1;
+//   * table protocol per tile (the order of the threads does not matter):
+//         old = T[h];  barrier;  ds_max(T[h], tail);  barrier;  r = T[h]
+//     leaves T as the sequential loop would, and r == tail identifies the
+//     latest run of each hash.  Hashes that occur in more than one run of the
+//     tile are resolved level by level (one barrier each): all runs that lost
+//     against run r ds_max their tail into pred[r]; the largest is r's
+//     predecessor and the root of the next level.  Text needs a few levels
+//     for a few threads per tile; the worst case (period-2 data) is bounded
+//     by the tile size.
 // ---------------------------------------------------------------------------
 constexpr int K1_THREADS = 1024;
+constexpr int K1_WAVES = K1_THREADS / 64;
+constexpr int K1_PER = 3;                              // positions per thread per tile
+constexpr int K1_SUB = K1_THREADS * K1_PER;            // positions per tile
+constexpr int K1_GROUPS = K1_SUB / 16 + 2;             // 16-byte groups staged per tile (+halo)
+constexpr int K1_TILE_BYTES = K1_GROUPS * 16;
+constexpr int K1_QCAP = 64 * K1_PER;                   // queue entries per wave (worst case)
+constexpr int K1_RELBITS = 12;                         // queue entry = idx << 12 | position in tile
+static_assert(K1_SUB <= (1 << K1_RELBITS), "tile position must fit the queue entry");
+static_assert(K1_GROUPS <= K1_THREADS, "one 16-byte group per thread");
 
-__device__ __forceinline__ uint32_t hash_at(const uint8_t *p, uint64_t mask, int shift) {
-  return (uint32_t)(((ld64(p) & mask) * kHashMul64) >> shift);
+// 8 bytes at byte offset `o` of an LDS byte image (3 aligned dword reads +
+// two funnel shifts; consecutive lanes read consecutive bytes, so the dword
+// reads broadcast and are conflict free).
+__device__ __forceinline__ uint2 lds_ld64(const uint32_t *img, uint32_t o) {
+  const uint32_t w = o >> 2, sh = o & 3;
+  const uint32_t d0 = img[w], d1 = img[w + 1], d2 = img[w + 2];
+  return make_uint2(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh));
+}
+
+// 16 bytes of the source buffer at byte offset `g` (relative to src_base),
+// zero-filled outside [0, total).
+__device__ __forceinline__ uint4 load_group(const uint8_t *src_base, int64_t g, int64_t total) {
+  if (g >= 0 && g + 16 <= total) {
+    uint4 v;
+    __builtin_memcpy(&v, src_base + g, 16);
+    return v;
+  }
+  uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+  for (int k = 0; k < 16; k++) {
+    int64_t a = g + k;
+    if (a >= 0 && a < total) w[k >> 2] |= (uint32_t)src_base[a] << (8 * (k & 3));
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits
+// for vmcnt(0), which would expose the latency of the chain stores and of the
+// next tile's prefetch at every barrier.  Nothing in K1 communicates through
+// global memory inside a launch, so LDS ordering is all the barrier must give.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Table protocol of one tile for the entries a wave has queued (see the K1
+// header comment).  NJ = entries per lane.  Levels use pred[]: pred[t] collects
+// (ds_max) the tails of the runs that lost against the run whose tail is at
+// tile position t; the largest is that run's predecessor and the next root.
+// A pred slot is used by one hash in one level of one tile, and stale values
+// are positions of earlier tiles (< sb), so pred never needs clearing.
+template <int NJ>
+__device__ __forceinline__ void k1_protocol(uint32_t *table, uint32_t *pred, uint32_t *flags,
+                                            const uint32_t *myq, uint32_t n, uint32_t sb,
+                                            uint32_t lane, uint32_t tid, uint32_t &level,
+                                            uint32_t *__restrict__ chain, int dbg) {
+  uint32_t idx[NJ], pos[NJ], tailpos[NJ], old[NJ], root[NJ];
+  bool have[NJ], head[NJ], unplaced[NJ], fresh[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const uint32_t e = j * 64 + lane;
+    have[j] = e < n;
+    const uint32_t ent = have[j] ? myq[e] : 0u;
+    idx[j] = ent >> K1_RELBITS;
+    pos[j] = sb + (ent & ((1u << K1_RELBITS) - 1));
+    // run folding: entry continues the previous entry (lane-1) when the hash
+    // is the same and the position is the next one  <=>  ent == prev + 1
+    const uint32_t prev = __shfl_up(ent, 1);
+    const bool same = lane > 0 && have[j] && ent == prev + 1;
+    const unsigned long long cont = __ballot(same);
+    head[j] = have[j] && !same;
+    tailpos[j] = pos[j];
+    if (head[j] && lane < 63) tailpos[j] += (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
+    old[j] = head[j] ? table[idx[j]] : 0u;
+  }
+  if (dbg & 8) return; // profiling aid
+  lds_barrier();
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+    if (head[j]) atomicMax(&table[idx[j]], tailpos[j]);
+  lds_barrier();
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    root[j] = head[j] ? table[idx[j]] : 0u; // tail of the latest run of this hash
+    unplaced[j] = head[j] && root[j] != tailpos[j];
+    if (unplaced[j]) atomicMax(&pred[root[j] - sb], tailpos[j]);
+    fresh[j] = head[j] && !unplaced[j]; // placed, predecessor still pending
+    any |= unplaced[j];
+  }
+  if (__ballot(any) && lane == 0) flags[level % 3] = 1;
+  lds_barrier();
+  while (flags[level % 3] && !(dbg & 4)) { // uniform: some run still has to be placed
+    if (tid == 0) flags[(level + 2) % 3] = 0;
+    level++;
+    any = false;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      if (fresh[j]) { // my predecessor is the best run that competed under me
+        const uint32_t m = pred[tailpos[j] - sb];
+        if (m >= sb && m != 0 && m < pos[j]) old[j] = m;
+        fresh[j] = false;
+      }
+      if (unplaced[j]) {
+        const uint32_t m = pred[root[j] - sb];
+        if (m == tailpos[j]) {
+          unplaced[j] = false;
+          fresh[j] = true;
+        } else {
+          // slots read at this level and slots written for the next level are
+          // disjoint (each run is placed once), so no barrier in between
+          root[j] = m;
+          atomicMax(&pred[m - sb], tailpos[j]);
+          any = true;
+        }
+      }
+    }
+    if (__ballot(any) && lane == 0) flags[level % 3] = 1;
+    lds_barrier();
+  }
+  if (tid == 0) flags[(level + 2) % 3] = 0;
+  level++;
+  if (dbg & 1) return; // profiling aid: no chain stores
+  // interior of a run: predecessor is pos-1 (position 0 counts as "empty",
+  // m4.go:152, so pos == 1 has none)
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+    if (have[j]) chain[pos[j]] = head[j] ? (old[j] ? pos[j] - old[j] : 0u) : (pos[j] > 1 ? 1u : 0u);
 }
 
 __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
-    const uint8_t *__restrict__ src_base, uint32_t *__restrict__ chain_base,
+    const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
-    int hash_len, int table_bits, int part_bits) {
+    int hash_len, int table_bits, int part_bits, int dbg) {
   extern __shared__ uint32_t lds[];
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
-  uint2 *dlist = reinterpret_cast<uint2 *>(lds + part_size);
-  uint32_t *dcnt = reinterpret_cast<uint32_t *>(dlist + K1_THREADS);
+  uint32_t *tile = lds + part_size;              // K1_TILE_BYTES/4 dwords
+  uint32_t *queues = tile + K1_TILE_BYTES / 4;   // K1_WAVES * K1_QCAP dwords
+  uint32_t *pred = queues + K1_WAVES * K1_QCAP;  // K1_SUB dwords, indexed by tile position
+  uint32_t *flags = pred + K1_SUB;               // 3 rotating level flags + 1 "multi" flag
 
   const int nparts = 1 << (table_bits - part_bits);
   // XCD-aware placement: blocks b and b+8 share an XCD, so give the nparts
@@ -74,55 +215,83 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   if (job >= (uint32_t)njobs) return;
 
   const Job J = jobs[job];
-  const uint8_t *src = src_base + J.src_off;
   uint32_t *chain = chain_base + J.chain_off;
   const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
+  uint32_t *myq = queues + (tid >> 6) * K1_QCAP;
 
   for (uint32_t k = tid; k < part_size; k += K1_THREADS)
     table[k] = table_io ? table_io[(q << part_bits) + k] : 0u;
-  if (tid == 0) *dcnt = 0;
-  __syncthreads();
+  for (uint32_t k = tid; k < K1_SUB; k += K1_THREADS) pred[k] = 0;
+  if (tid < 4) flags[tid] = 0;
 
+  // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces:
+  // only the upper dword of the low 64 product bits is needed (table_bits <= 24)
   const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
-  const int shift = 64 - table_bits;
+  const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
+  const uint32_t mul_lo = (uint32_t)kHashMul64, mul_hi = (uint32_t)(kHashMul64 >> 32);
+  const uint32_t shift = 32 - table_bits;
   const uint32_t idx_mask = part_size - 1;
   const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
 
-  for (uint32_t base = J.start; base < end; base += K1_THREADS) {
-    const uint32_t pos = base + tid;
-    bool in = false;
-    uint32_t idx = 0, old = 0;
-    if (pos < end) {
-      uint32_t h = hash_at(src + pos, mask, shift);
-      in = (h >> part_bits) == q;
-      idx = h & idx_mask;
+  // staged tile: bytes [A, A + K1_TILE_BYTES) of the source buffer, where A is
+  // the 16-byte aligned offset at or below the tile's first position
+  auto tile_origin = [&](uint32_t base) -> int64_t {
+    return (int64_t)((J.src_off + base) & ~(uint64_t)15);
+  };
+  uint4 pre = make_uint4(0, 0, 0, 0);
+  if (J.start < end && tid < K1_GROUPS)
+    pre = load_group(src_base, tile_origin(J.start) + 16 * (int64_t)tid, (int64_t)src_total);
+
+  uint32_t level = 0; // running level counter, selects the flag word
+#pragma unroll 1
+  for (uint32_t sb = J.start; sb < end; sb += K1_SUB) {
+    lds_barrier(); // previous tile fully consumed (and LDS init done)
+    if (tid < K1_GROUPS) reinterpret_cast<uint4 *>(tile)[tid] = pre;
+    const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
+    if (sb + K1_SUB < end && tid < K1_GROUPS) // prefetch the next tile meanwhile
+      pre = load_group(src_base, tile_origin(sb + K1_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
+    lds_barrier();
+
+    // ---- hash K1_PER positions per lane, compact this partition's into myq ----
+    uint32_t n = 0; // wave-uniform
+#pragma unroll
+    for (int k = 0; k < K1_PER; k++) {
+      const uint32_t rel = k * K1_THREADS + tid; // wave covers 64 consecutive positions per k
+      const uint2 v = lds_ld64(tile, lds_off0 + rel);
+      const uint32_t lo = v.x & mask_lo, hi = v.y & mask_hi;
+      const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
+      const bool in = sb + rel < end && (h >> part_bits) == q;
+      const unsigned long long bal = __ballot(in);
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      if (in) myq[n + below] = ((h & idx_mask) << K1_RELBITS) | rel;
+      n += (uint32_t)__builtin_popcountll(bal);
     }
-    if (in) old = table[idx];
-    __syncthreads();
-    if (in) atomicMax(&table[idx], pos);
-    __syncthreads();
-    const bool loser = in && table[idx] != pos;
-    if (__syncthreads_or(loser)) {
-      if (loser) {
-        uint32_t k = atomicAdd(dcnt, 1u);
-        dlist[k] = make_uint2(idx, pos);
-      }
-      __syncthreads();
-      const uint32_t cnt = *dcnt;
-      if (in) {
-        for (uint32_t k = 0; k < cnt; k++) {
-          uint2 e = dlist[k];
-          if (e.x == idx && e.y < pos && e.y > old) old = e.y;
-        }
-      }
-      __syncthreads();
-      if (tid == 0) *dcnt = 0;
-    }
-    if (in) chain[pos] = old ? pos - old : 0u;
+    // the wave reads back what its own lanes wrote: LDS ops of one wave are
+    // executed in order, only the compiler must not reorder them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    if (dbg & 2) continue; // profiling aid: hashing + compaction only
+    // Dense entries.  A wave normally holds ~64*K1_PER/nparts <= 64 entries,
+    // one per lane; when some wave has more (one partition gets almost
+    // everything, e.g. zero pages) the whole workgroup takes the general
+    // K1_PER-entries-per-lane path.  The choice is workgroup-uniform because
+    // both paths contain barriers.
+    if (n > 64 && lane == 0) flags[3] = 1;
+    lds_barrier();
+    const bool multi = flags[3] != 0;
+    if (!multi)
+      k1_protocol<1>(table, pred, flags, myq, n, sb, lane, tid, level, chain, dbg);
+    else
+      k1_protocol<K1_PER>(table, pred, flags, myq, n, sb, lane, tid, level, chain, dbg);
+    if (multi && tid == 0) flags[3] = 0; // next tile's barrier orders this store
   }
 
   if (table_io) {
-    __syncthreads();
+    lds_barrier();
     for (uint32_t k = tid; k < part_size; k += K1_THREADS)
       table_io[(q << part_bits) + k] = table[k];
   }
