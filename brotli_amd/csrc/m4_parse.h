@@ -67,6 +67,18 @@ M4G_HD uint64_t ld64(const uint8_t *p) {
   return v;
 }
 
+// Memory accessor of the parse: every read of the input bytes and of the chain
+// array goes through one of these, so kernels can substitute a staged (LDS)
+// view for the positions a lane is currently walking (kernels.h, StagedMem).
+struct GlobalMem {
+  const uint8_t *src;
+  const uint32_t *chain;
+  M4G_HD uint8_t ld8(int32_t p) const { return src[p]; }
+  M4G_HD uint32_t ld32(int32_t p) const { return m4g::ld32(src + p); }
+  M4G_HD uint64_t ld64(int32_t p) const { return m4g::ld64(src + p); }
+  M4G_HD uint32_t chain_at(int32_t p) const { return chain[p]; }
+};
+
 M4G_HD int32_t bitlen32(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
 
 // m4.go:59-61 (64-bit: lengths reach 2^25 in streaming mode)
@@ -76,14 +88,15 @@ M4G_HD int64_t score(const AbsMatch &m, int32_t cost) {
 }
 
 // m4.go:293-324: first index >= j where src[i+k] != src[j+k], or len.
-M4G_HD int32_t extend_fwd(const uint8_t *src, int32_t len, int32_t i, int32_t j) {
+template <class Mem>
+M4G_HD int32_t extend_fwd(const Mem &M, int32_t len, int32_t i, int32_t j) {
   while (j + 8 < len) {
-    uint64_t a = ld64(src + i), b = ld64(src + j);
+    uint64_t a = M.ld64(i), b = M.ld64(j);
     if (a != b) return j + (int32_t)(__builtin_ctzll(a ^ b) >> 3);
     i += 8;
     j += 8;
   }
-  while (j < len && src[i] == src[j]) {
+  while (j < len && M.ld8(i) == M.ld8(j)) {
     i++;
     j++;
   }
@@ -91,11 +104,11 @@ M4G_HD int32_t extend_fwd(const uint8_t *src, int32_t len, int32_t i, int32_t j)
 }
 
 // m4.go:328-339
-M4G_HD AbsMatch extend2(const uint8_t *src, int32_t len, int32_t start,
-                        int32_t cand, int32_t lo) {
+template <class Mem>
+M4G_HD AbsMatch extend2(const Mem &M, int32_t len, int32_t start, int32_t cand, int32_t lo) {
   AbsMatch m;
-  m.end = extend_fwd(src, len, cand + 4, start + 4);
-  while (start > lo && cand > 0 && src[start - 1] == src[cand - 1]) {
+  m.end = extend_fwd(M, len, cand + 4, start + 4);
+  while (start > lo && cand > 0 && M.ld8(start - 1) == M.ld8(cand - 1)) {
     start--;
     cand--;
   }
@@ -148,15 +161,14 @@ M4G_HD void state_init(ParseState &S, int32_t start, uint32_t seed_prev_distance
 }
 
 // Runs loop iterations of m4.go:112-260 while S.i < stop (stop <= len-7).
-// `src`/`chain` are indexed by buffer position; `len` is the buffer length
-// (forward extension may read up to len, never past it).
+// M reads the input bytes / chain array by buffer position; `len` is the
+// buffer length (forward extension may read up to len, never past it).
 // With STOP_AT_FLUSH the function returns true right after a loop-top flush
 // (state saved at that position, before the repeat probe); it returns false
 // when the range is exhausted.
-template <bool STOP_AT_FLUSH = false, class Sink>
-M4G_HD bool parse_range(const uint8_t *__restrict__ src, int32_t len,
-                        const uint32_t *__restrict__ chain, const ParseParams &P,
-                        ParseState &S, int32_t stop, Sink &sink) {
+template <bool STOP_AT_FLUSH = false, class Mem, class Sink>
+M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseState &S,
+                        int32_t stop, Sink &sink) {
   int32_t i = S.i;
   while (i < stop) {
     // A. m4.go:113-126
@@ -174,8 +186,8 @@ M4G_HD bool parse_range(const uint8_t *__restrict__ src, int32_t len,
       int32_t c = p - (int32_t)S.prev_dist;
       if (c < 0) {
         S.error = 1; // the Go code would panic on the slice bounds
-      } else if (ld32(src + p) == ld32(src + c)) {
-        AbsMatch m = extend2(src, len, p, c, S.next_emit + 1);
+      } else if (M.ld32(p) == M.ld32(c)) {
+        AbsMatch m = extend2(M, len, p, c, S.next_emit + 1);
         if (m.end - m.start >= P.min_length) S.m0 = m;
       }
     }
@@ -190,7 +202,7 @@ M4G_HD bool parse_range(const uint8_t *__restrict__ src, int32_t len,
     }
 
     // C+D. candidate = table[h] before insertion == i - chain[i]
-    uint32_t d = chain[i];
+    uint32_t d = M.chain_at(i);
     if (d == 0 || d > (uint32_t)P.max_distance) {
       i++;
       continue;
@@ -200,9 +212,9 @@ M4G_HD bool parse_range(const uint8_t *__restrict__ src, int32_t len,
     // E. m4.go:156-181
     AbsMatch cur{0, 0, 0};
     int64_t cur_score = 0;
-    const uint32_t w = ld32(src + i);
-    if (ld32(src + cand) == w) {
-      AbsMatch m = extend2(src, len, i, cand, S.next_emit);
+    const uint32_t w = M.ld32(i);
+    if (M.ld32(cand) == w) {
+      AbsMatch m = extend2(M, len, i, cand, S.next_emit);
       if (m.end - m.start > P.min_length) {
         int64_t sc = score(m, P.distance_bit_cost);
         if (sc > 0) {
@@ -212,14 +224,14 @@ M4G_HD bool parse_range(const uint8_t *__restrict__ src, int32_t len,
       }
     }
     for (int32_t j = 0; j < P.chain_length; j++) {
-      uint32_t dd = chain[cand];
+      uint32_t dd = M.chain_at(cand);
       if (dd == 0) break;
       // Go: candidate -= int(delta) in 64-bit; dd > cand means candidate <= 0
       if (dd >= (uint32_t)cand) break;
       cand -= (int32_t)dd;
       if (i - cand > P.max_distance) break;
-      if (ld32(src + cand) == w) {
-        AbsMatch m = extend2(src, len, i, cand, S.next_emit);
+      if (M.ld32(cand) == w) {
+        AbsMatch m = extend2(M, len, i, cand, S.next_emit);
         if (m.end - m.start > P.min_length) {
           int64_t sc = score(m, P.distance_bit_cost);
           if (sc > cur_score) {
@@ -265,12 +277,12 @@ M4G_HD bool parse_range(const uint8_t *__restrict__ src, int32_t len,
             // m4.go:236-252: look for a closer source for the trimmed match
             int32_t pos = m2.start;
             for (;;) {
-              uint32_t dd = chain[pos];
+              uint32_t dd = M.chain_at(pos);
               if (dd == 0) break;
               if ((int64_t)pos - (int64_t)dd <= (int64_t)m2.match) break;
               pos -= (int32_t)dd;
               int32_t k = 0;
-              while (k < mlen && src[m2.start + k] == src[pos + k]) k++;
+              while (k < mlen && M.ld8(m2.start + k) == M.ld8(pos + k)) k++;
               if (k == mlen) {
                 m2.match = pos;
                 break;

@@ -68,22 +68,20 @@ M4G_HD int32_t block_end(const SpecGeom &g, int32_t k) {
 }
 
 // Phase A for block k.
-template <class Sink>
-M4G_HD void spec_parse_block(const uint8_t *__restrict__ src, int32_t len,
-                             const uint32_t *__restrict__ chain, const ParseParams &P,
+template <class Mem, class Sink>
+M4G_HD void spec_parse_block(const Mem &M, int32_t len, const ParseParams &P,
                              const SpecGeom &g, int32_t k, uint32_t seed_prev, ParseState &E,
                              Sink &sink) {
   state_init(E, block_begin(g, k), k == 0 ? seed_prev : 0u);
-  parse_range<false>(src, len, chain, P, E, block_end(g, k), sink);
+  parse_range<false>(M, len, P, E, block_end(g, k), sink);
   if (k == g.nblocks - 1) parse_finish(len, P, E, sink);
 }
 
 // Phase B for block k >= 1.  T is the true state entering the block and is
 // updated to the true state entering block k+1.  Returns true when the block
 // synchronised with its speculative parse.
-template <class Sink>
-M4G_HD bool stitch_block(const uint8_t *__restrict__ src, int32_t len,
-                         const uint32_t *__restrict__ chain, const ParseParams &P,
+template <class Mem, class Sink>
+M4G_HD bool stitch_block(const Mem &M, int32_t len, const ParseParams &P,
                          const SpecGeom &g, int32_t k, const Rec *__restrict__ spec,
                          uint32_t n_spec, const ParseState &E, ParseState &T, Sink &sink,
                          uint32_t &keep_from) {
@@ -91,7 +89,7 @@ M4G_HD bool stitch_block(const uint8_t *__restrict__ src, int32_t len,
   uint32_t j = 0;
   bool synced = false;
   while (T.i < stop) {
-    if (!parse_range<true>(src, len, chain, P, T, stop, sink)) break;
+    if (!parse_range<true>(M, len, P, T, stop, sink)) break;
     // a flush just happened: the last record ends at T.next_emit (== T.i)
     const int32_t e = T.next_emit;
     while (j < n_spec && rec_end(spec[j]) < e) j++;

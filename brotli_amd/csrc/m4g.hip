@@ -159,8 +159,8 @@ int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint3
   const ParseParams P = parse_params(p);
   const uint64_t lanes = (uint64_t)njobs * w.L.kmax;
   const unsigned g3 = (unsigned)((lanes + K3_THREADS - 1) / K3_THREADS);
-  hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs, w.E,
-                     w.desc, d_errors, njobs, w.L, P);
+  hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), 0, st, d_src, src_total, d_chain, d_jobs,
+                     w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
   HIP_TRY(hipGetLastError());
   if (w.L.kmax > 1) {
     hipLaunchKernelGGL(k3b_stitch, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
@@ -287,7 +287,7 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
     return rc;
   }
   hipError_t e;
-  if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 64)) != hipSuccess ||
+  if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 4096)) != hipSuccess ||
       (e = hipMalloc(&b->d_pf, b->pf_cap * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_counts, max_chunks * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_errors, 64)) != hipSuccess ||
@@ -679,7 +679,7 @@ int ctx_reserve(m4g_ctx *c, size_t need) {
   while (nc < need) nc *= 2;
   uint8_t *nh = nullptr;
   uint32_t *nch = nullptr;
-  if (hipMalloc(&nh, nc + 64) != hipSuccess || hipMalloc(&nch, nc * 4 + 64) != hipSuccess) {
+  if (hipMalloc(&nh, nc + 64) != hipSuccess || hipMalloc(&nch, nc * 4 + 4096) != hipSuccess) {
     (void)hipFree(nh);
     (void)hipFree(nch);
     return fail(M4G_ERR_NO_MEMORY, "growing the history buffer failed");

@@ -49,7 +49,8 @@ int64_t sim_find_matches(const uint8_t *src, int32_t n, int max_distance, int mi
   VecSink sink;
   ParseState S;
   state_init(S, 0, seed_prev);
-  parse_range(src, n, chain.data(), P, S, n - 7, sink);
+  GlobalMem M{src, chain.data()};
+  parse_range(M, n, P, S, n - 7, sink);
   parse_finish(n, P, S, sink);
   if ((int64_t)sink.v.size() > out_cap) return -(int64_t)sink.v.size();
   for (auto &r : sink.v) r.lit_start &= ~kRecFlushBit;
@@ -70,13 +71,14 @@ int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, i
   ParseParams P{max_distance, min_length, hash_len, chain_length, distance_bit_cost};
   std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
   build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
+  GlobalMem M{src, chain.data()};
   const SpecGeom g = spec_geom(0, (uint32_t)n, sub_block);
   const int K = g.nblocks;
   std::vector<std::vector<Rec>> RS(K);
   std::vector<ParseState> E(K);
   for (int k = 0; k < K; k++) {
     VecSink sink;
-    spec_parse_block(src, n, chain.data(), P, g, k, seed_prev, E[k], sink);
+    spec_parse_block(M, n, P, g, k, seed_prev, E[k], sink);
     RS[k] = std::move(sink.v);
   }
   std::vector<Rec> result = RS[0];
@@ -86,7 +88,7 @@ int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, i
     VecSink st;
     uint32_t keep = 0;
     int32_t i0 = T.i;
-    bool ok = stitch_block(src, n, chain.data(), P, g, k, RS[k].data(), (uint32_t)RS[k].size(),
+    bool ok = stitch_block(M, n, P, g, k, RS[k].data(), (uint32_t)RS[k].size(),
                            E[k], T, st, keep);
     synced += ok;
     if (ok) {
