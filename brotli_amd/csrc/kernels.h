@@ -72,6 +72,7 @@ constexpr int K1_TILE_BYTES = K1_GROUPS * 16;
 constexpr int K1_QCAP = 64 * K1_PER;                   // queue entries per wave (worst case)
 constexpr int K1_RELBITS = 12;                         // queue entry = idx << 12 | position in tile
 static_assert(K1_SUB <= (1 << K1_RELBITS), "tile position must fit the queue entry");
+constexpr int K1_MAX_CHECK_BITS = 32 - K1_RELBITS - 15;  // room left in a queue entry
 static_assert(K1_GROUPS <= K1_THREADS, "one 16-byte group per thread");
 
 // 8 bytes at byte offset `o` of an LDS byte image (3 aligned dword reads +
@@ -114,42 +115,50 @@ __device__ __forceinline__ void lds_barrier() {
 // tile position t; the largest is that run's predecessor and the next root.
 // A pred slot is used by one hash in one level of one tile, and stale values
 // are positions of earlier tiles (< sb), so pred never needs clearing.
+// A table / pred value is  V(p) = p << cb | chk(p):  the position in the high
+// bits (so ds_max orders by position) and cb check bits of the 4 bytes at p.
 template <int NJ>
 __device__ __forceinline__ void k1_protocol(uint32_t *table, uint32_t *pred, uint32_t *flags,
                                             const uint32_t *myq, uint32_t n, uint32_t sb,
                                             uint32_t lane, uint32_t tid, uint32_t &level,
-                                            uint32_t *__restrict__ chain, int dbg) {
-  uint32_t idx[NJ], pos[NJ], tailpos[NJ], old[NJ], root[NJ];
+                                            uint32_t *__restrict__ chain, uint32_t cb, int dbg) {
+  constexpr uint32_t kEntMask = (1u << (K1_RELBITS + 15)) - 1; // idx | rel, without check bits
+  const uint32_t cmask = (1u << cb) - 1;
+  uint32_t idx[NJ], pos[NJ], chk[NJ], pchk[NJ], vtail[NJ], old[NJ], root[NJ];
   bool have[NJ], head[NJ], unplaced[NJ], fresh[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     const uint32_t e = j * 64 + lane;
     have[j] = e < n;
     const uint32_t ent = have[j] ? myq[e] : 0u;
-    idx[j] = ent >> K1_RELBITS;
+    idx[j] = (ent & kEntMask) >> K1_RELBITS;
     pos[j] = sb + (ent & ((1u << K1_RELBITS) - 1));
+    chk[j] = (ent >> (K1_RELBITS + 15)) & cmask;
     // run folding: entry continues the previous entry (lane-1) when the hash
-    // is the same and the position is the next one  <=>  ent == prev + 1
+    // is the same and the position is the next one
     const uint32_t prev = __shfl_up(ent, 1);
-    const bool same = lane > 0 && have[j] && ent == prev + 1;
+    pchk[j] = (prev >> (K1_RELBITS + 15)) & cmask;
+    const bool same = lane > 0 && have[j] && (ent & kEntMask) == (prev & kEntMask) + 1;
     const unsigned long long cont = __ballot(same);
     head[j] = have[j] && !same;
-    tailpos[j] = pos[j];
-    if (head[j] && lane < 63) tailpos[j] += (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
+    uint32_t runlen1 = 0; // run length - 1
+    if (head[j] && lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
+    const uint32_t tchk = __shfl(chk[j], (int)(lane + runlen1)); // check bits of the run's tail
+    vtail[j] = ((pos[j] + runlen1) << cb) | tchk;
     old[j] = head[j] ? table[idx[j]] : 0u;
   }
   if (dbg & 8) return; // profiling aid
   lds_barrier();
 #pragma unroll
   for (int j = 0; j < NJ; j++)
-    if (head[j]) atomicMax(&table[idx[j]], tailpos[j]);
+    if (head[j]) atomicMax(&table[idx[j]], vtail[j]);
   lds_barrier();
   bool any = false;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    root[j] = head[j] ? table[idx[j]] : 0u; // tail of the latest run of this hash
-    unplaced[j] = head[j] && root[j] != tailpos[j];
-    if (unplaced[j]) atomicMax(&pred[root[j] - sb], tailpos[j]);
+    root[j] = head[j] ? table[idx[j]] : 0u; // latest run of this hash
+    unplaced[j] = head[j] && root[j] != vtail[j];
+    if (unplaced[j]) atomicMax(&pred[(root[j] >> cb) - sb], vtail[j]);
     fresh[j] = head[j] && !unplaced[j]; // placed, predecessor still pending
     any |= unplaced[j];
   }
@@ -162,20 +171,21 @@ __device__ __forceinline__ void k1_protocol(uint32_t *table, uint32_t *pred, uin
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       if (fresh[j]) { // my predecessor is the best run that competed under me
-        const uint32_t m = pred[tailpos[j] - sb];
-        if (m >= sb && m != 0 && m < pos[j]) old[j] = m;
+        const uint32_t m = pred[(vtail[j] >> cb) - sb];
+        const uint32_t mp = m >> cb;
+        if (mp >= sb && mp != 0 && mp < pos[j]) old[j] = m;
         fresh[j] = false;
       }
       if (unplaced[j]) {
-        const uint32_t m = pred[root[j] - sb];
-        if (m == tailpos[j]) {
+        const uint32_t m = pred[(root[j] >> cb) - sb];
+        if (m == vtail[j]) {
           unplaced[j] = false;
           fresh[j] = true;
         } else {
           // slots read at this level and slots written for the next level are
           // disjoint (each run is placed once), so no barrier in between
           root[j] = m;
-          atomicMax(&pred[m - sb], tailpos[j]);
+          atomicMax(&pred[(m >> cb) - sb], vtail[j]);
           any = true;
         }
       }
@@ -186,17 +196,24 @@ __device__ __forceinline__ void k1_protocol(uint32_t *table, uint32_t *pred, uin
   if (tid == 0) flags[(level + 2) % 3] = 0;
   level++;
   if (dbg & 1) return; // profiling aid: no chain stores
-  // interior of a run: predecessor is pos-1 (position 0 counts as "empty",
-  // m4.go:152, so pos == 1 has none)
 #pragma unroll
-  for (int j = 0; j < NJ; j++)
-    if (have[j]) chain[pos[j]] = head[j] ? (old[j] ? pos[j] - old[j] : 0u) : (pos[j] > 1 ? 1u : 0u);
+  for (int j = 0; j < NJ; j++) {
+    if (!have[j]) continue;
+    uint32_t c;
+    if (head[j]) {
+      const uint32_t op = old[j] >> cb; // position 0 counts as "empty" (m4.go:152)
+      c = op ? ((pos[j] - op) | ((old[j] & cmask) == chk[j] ? kChainMaybe : 0u)) : 0u;
+    } else { // interior of a run: the predecessor is pos-1
+      c = pos[j] > 1 ? (1u | (pchk[j] == chk[j] ? kChainMaybe : 0u)) : 0u;
+    }
+    chain[pos[j]] = c;
+  }
 }
 
 __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
-    int hash_len, int table_bits, int part_bits, int dbg) {
+    int hash_len, int table_bits, int part_bits, int check_bits, int dbg) {
   extern __shared__ uint32_t lds[];
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   const uint32_t mul_lo = (uint32_t)kHashMul64, mul_hi = (uint32_t)(kHashMul64 >> 32);
   const uint32_t shift = 32 - table_bits;
   const uint32_t idx_mask = part_size - 1;
+  const uint32_t cb = (uint32_t)check_bits; // <= 32 - K1_RELBITS - 15 and positions << cb fit 32 bits
   const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
 
   // staged tile: bytes [A, A + K1_TILE_BYTES) of the source buffer, where A is
@@ -265,7 +283,9 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
       const unsigned long long bal = __ballot(in);
       const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-      if (in) myq[n + below] = ((h & idx_mask) << K1_RELBITS) | rel;
+      // check bits of the first 4 bytes (top bits of a multiplicative hash)
+      const uint32_t ck = cb ? (v.x * 0x9E3779B1u) >> (32 - cb) : 0u;
+      if (in) myq[n + below] = (ck << (K1_RELBITS + 15)) | ((h & idx_mask) << K1_RELBITS) | rel;
       n += (uint32_t)__builtin_popcountll(bal);
     }
     // the wave reads back what its own lanes wrote: LDS ops of one wave are
@@ -284,9 +304,9 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     lds_barrier();
     const bool multi = flags[3] != 0;
     if (!multi)
-      k1_protocol<1>(table, pred, flags, myq, n, sb, lane, tid, level, chain, dbg);
+      k1_protocol<1>(table, pred, flags, myq, n, sb, lane, tid, level, chain, cb, dbg);
     else
-      k1_protocol<K1_PER>(table, pred, flags, myq, n, sb, lane, tid, level, chain, dbg);
+      k1_protocol<K1_PER>(table, pred, flags, myq, n, sb, lane, tid, level, chain, cb, dbg);
     if (multi && tid == 0) flags[3] = 0; // next tile's barrier orders this store
   }
 
@@ -372,6 +392,9 @@ struct StagedMem {
     }
     return m4g::ld64(src + p);
   }
+  // match sources are (almost) never inside the staged range: always global,
+  // no branch, so the loads of one iteration issue back to back
+  __device__ __forceinline__ uint64_t far64(int32_t p) const { return m4g::ld64(src + p); }
   __device__ __forceinline__ uint32_t chain_at(int32_t p) const {
     const uint32_t o = (uint32_t)(p - w0);
     if (o < (uint32_t)K3_W) return lch[o];

@@ -76,6 +76,8 @@ struct GlobalMem {
   M4G_HD uint8_t ld8(int32_t p) const { return src[p]; }
   M4G_HD uint32_t ld32(int32_t p) const { return m4g::ld32(src + p); }
   M4G_HD uint64_t ld64(int32_t p) const { return m4g::ld64(src + p); }
+  // read of a match source: far from the positions being walked
+  M4G_HD uint64_t far64(int32_t p) const { return m4g::ld64(src + p); }
   M4G_HD uint32_t chain_at(int32_t p) const { return chain[p]; }
 };
 
@@ -116,6 +118,51 @@ M4G_HD AbsMatch extend2(const Mem &M, int32_t len, int32_t start, int32_t cand, 
   m.match = cand;
   return m;
 }
+
+// 4-byte equality test (m4.go:131,159,175) and extendMatch2 in one step.
+// The reference does them as a chain of small dependent reads; on the GPU every
+// read of a match SOURCE is a global-memory round trip, so the common case is
+// served by two independent 8-byte reads of the source (at cand and cand-8):
+// they decide the equality test, the first 8 bytes of the forward extension
+// and up to 8 bytes of the backward extension.  The result is the same
+// (start, end, match) extendMatch2 computes -- extension is plain byte
+// comparison -- only the read pattern differs.
+template <class Mem>
+M4G_HD bool match_at(const Mem &M, int32_t len, int32_t pos, int32_t cand, int32_t lo,
+                     AbsMatch &m) {
+  if (cand >= 8 && pos + 8 <= len) {
+    const uint64_t cf = M.ld64(cand), cb = M.ld64(cand - 8);
+    const uint64_t x = cf ^ M.ld64(pos);
+    if ((uint32_t)x != 0) return false;
+    m.end = x != 0 ? pos + (int32_t)(__builtin_ctzll(x) >> 3)
+                   : extend_fwd(M, len, cand + 8, pos + 8);
+    // backward: at most pos-lo steps (start > lo) and at most cand steps (candidate > 0)
+    const int32_t maxb = (pos - lo) < cand ? (pos - lo) : cand;
+    int32_t nb = 0;
+    if (maxb > 0) {
+      const uint64_t y = cb ^ M.ld64(pos - 8);
+      nb = y != 0 ? (int32_t)(__builtin_clzll(y) >> 3) : 8;
+      if (nb > maxb) nb = maxb;
+      if (nb == 8)
+        while (nb < maxb && M.ld8(pos - nb - 1) == M.ld8(cand - nb - 1)) nb++;
+    }
+    m.start = pos - nb;
+    m.match = cand - nb;
+    return true;
+  }
+  if (M.ld32(cand) != M.ld32(pos)) return false;
+  m = extend2(M, len, pos, cand, lo);
+  return true;
+}
+
+// Chain entry layout: bits 0..30 = distance to the previous position with the
+// same hash (0: none); bit 31 = "the 4 bytes there MAY equal the 4 bytes here".
+// K1 keeps a few check bits of every position's first 4 bytes next to the
+// position in its hash table; when they differ the parse can skip the random
+// read of the candidate (m4.go:159) -- on text that is ~95 % of the literal
+// positions.  A set bit promises nothing, a clear bit is definite.
+constexpr uint32_t kChainMaybe = 0x80000000u;
+constexpr uint32_t kChainDelta = 0x7FFFFFFFu;
 
 // matchEmitter.emit (emitter.go:27-34) into a caller-provided sink.
 // Bit 31 of Rec.lit_start marks a record emitted as the newest pending match
@@ -160,16 +207,71 @@ M4G_HD void state_init(ParseState &S, int32_t start, uint32_t seed_prev_distance
   S.error = 0;
 }
 
+// Candidate evaluation from bytes that are already in registers: cf/cf2 = the
+// 16 bytes at cand, cb = the 8 bytes before cand.  Same result as match_at.
+template <class Mem>
+M4G_HD bool match_regs(const Mem &M, int32_t len, int32_t pos, int32_t cand, int32_t lo,
+                       uint64_t cf, uint64_t cf2, bool have2, uint64_t cb, AbsMatch &m) {
+  const uint64_t x = cf ^ M.ld64(pos);
+  if ((uint32_t)x != 0) return false;
+  if (x != 0) {
+    m.end = pos + (int32_t)(__builtin_ctzll(x) >> 3);
+  } else if (have2) {
+    const uint64_t x2 = cf2 ^ M.ld64(pos + 8);
+    m.end = x2 != 0 ? pos + 8 + (int32_t)(__builtin_ctzll(x2) >> 3)
+                    : extend_fwd(M, len, cand + 16, pos + 16);
+  } else {
+    m.end = extend_fwd(M, len, cand + 8, pos + 8);
+  }
+  const int32_t maxb = (pos - lo) < cand ? (pos - lo) : cand;
+  int32_t nb = 0;
+  if (maxb > 0) {
+    const uint64_t y = cb ^ M.ld64(pos - 8);
+    nb = y != 0 ? (int32_t)(__builtin_clzll(y) >> 3) : 8;
+    if (nb > maxb) nb = maxb;
+    if (nb == 8)
+      while (nb < maxb && M.ld8(pos - nb - 1) == M.ld8(cand - nb - 1)) nb++;
+  }
+  m.start = pos - nb;
+  m.match = cand - nb;
+  return true;
+}
+
+// Next loop position after position i has been handled: inside a pending
+// match the reference only inserts hashes (K1 did that) except at position
+// End+2-HashLen, which is searched (m4.go:149-151); so jump there, or to End.
+M4G_HD int32_t next_pos(const ParseState &S, const ParseParams &P, int32_t i) {
+  if (S.m0.end == 0) return i + 1;
+  const int32_t probe = S.m0.end + 2 - P.hash_len;
+  return (probe > i && probe < S.m0.end) ? probe : S.m0.end;
+}
+
 // Runs loop iterations of m4.go:112-260 while S.i < stop (stop <= len-7).
 // M reads the input bytes / chain array by buffer position; `len` is the
 // buffer length (forward extension may read up to len, never past it).
 // With STOP_AT_FLUSH the function returns true right after a loop-top flush
 // (state saved at that position, before the repeat probe); it returns false
 // when the range is exhausted.
+//
+// Loop invariant at the top: no match pending, or i == m0.End (flush), or
+// i == m0.End+2-HashLen (the one searched position inside a pending match).
+//
+// GPU note: every lane of a wave runs its own copy of this loop, and divergent
+// branches execute one after the other.  A global-memory read inside a
+// divergent branch therefore exposes its full latency to the whole wave.  So
+// all reads of match SOURCES that an iteration can need (the repeat-probe
+// bytes and the 24 bytes around the hash candidate) are issued together,
+// unconditionally (lanes that do not need them read position 0), before any
+// branch; the branches then work on registers.  Only rare continuations
+// (matches longer than 16 bytes, chain hops) read memory inside a branch.
 template <bool STOP_AT_FLUSH = false, class Mem, class Sink>
 M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseState &S,
                         int32_t stop, Sink &sink) {
   int32_t i = S.i;
+  // 8 source bytes of the repeat probe, kept across iterations: consecutive
+  // literal positions probe consecutive addresses (same prev_dist).
+  uint64_t pc_bytes = 0;
+  int32_t pc_base = -0x40000000;
   while (i < stop) {
     // A. m4.go:113-126
     if (S.m0.end != 0 && i >= S.m0.end) {
@@ -179,43 +281,66 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
         return true;
       }
     }
+    const bool was_empty = S.m0.end == 0;
+
+    // ---- what this iteration may need from far memory ----------------------
+    const int32_t p = i + 1;
+    const int32_t c = p - (int32_t)S.prev_dist;
+    const bool do_probe = was_empty && S.have_prev && c >= 0;
+    const bool probe_err = was_empty && S.have_prev && c < 0;
+    const uint32_t pc_off = (uint32_t)(c - pc_base);
+    const bool probe_load = do_probe && pc_off > 4 && c + 8 <= len;
+
+    const uint32_t ce = M.chain_at(i);
+    const uint32_t d = ce & kChainDelta;
+    const bool cand_ok = d != 0 && d <= (uint32_t)P.max_distance;
+    int32_t cand = i - (int32_t)d;
+    const bool cand_fast = cand_ok && (ce & kChainMaybe) && cand >= 8; // i+8 <= len always
+    const bool cand_fast2 = cand_fast && i + 16 <= len;
+
+    const uint64_t pl = M.far64(probe_load ? c : 0);
+    const uint64_t cf = M.far64(cand_fast ? cand : 0);
+    const uint64_t cb = M.far64(cand_fast ? cand - 8 : 0);
+    const uint64_t cf2 = M.far64(cand_fast2 ? cand + 8 : 0);
 
     // B. m4.go:128-138 repeat match one byte after the current position
-    if (S.m0.end == 0 && S.have_prev) {
-      int32_t p = i + 1;
-      int32_t c = p - (int32_t)S.prev_dist;
-      if (c < 0) {
-        S.error = 1; // the Go code would panic on the slice bounds
-      } else if (M.ld32(p) == M.ld32(c)) {
-        AbsMatch m = extend2(M, len, p, c, S.next_emit + 1);
-        if (m.end - m.start >= P.min_length) S.m0 = m;
+    if (probe_err) S.error = 1; // the Go code would panic on the slice bounds
+    if (do_probe) {
+      uint32_t cw;
+      if (pc_off <= 4) {
+        cw = (uint32_t)(pc_bytes >> (8 * pc_off));
+      } else if (probe_load) {
+        pc_bytes = pl;
+        pc_base = c;
+        cw = (uint32_t)pl;
+      } else {
+        cw = M.ld32(c);
       }
+      AbsMatch m;
+      if (cw == M.ld32(p) && match_at(M, len, p, c, S.next_emit + 1, m) &&
+          m.end - m.start >= P.min_length)
+        S.m0 = m;
     }
 
-    // D. m4.go:149-151; positions in between only insert hashes (done by K1)
-    if (S.m0.end != 0 && i < S.m0.end) {
-      int32_t probe = S.m0.end + 2 - P.hash_len;
-      if (i != probe) {
-        i = (probe > i && probe < S.m0.end) ? probe : S.m0.end;
-        continue;
-      }
-    }
-
-    // C+D. candidate = table[h] before insertion == i - chain[i]
-    uint32_t d = M.chain_at(i);
-    if (d == 0 || d > (uint32_t)P.max_distance) {
-      i++;
+    // D. m4.go:149-151: a match set just now makes i an interior position
+    if (was_empty && S.m0.end != 0 && i != S.m0.end + 2 - P.hash_len) {
+      i = next_pos(S, P, i);
       continue;
     }
-    int32_t cand = i - (int32_t)d;
+    // m4.go:152-154
+    if (!cand_ok) {
+      i = next_pos(S, P, i);
+      continue;
+    }
 
     // E. m4.go:156-181
     AbsMatch cur{0, 0, 0};
     int64_t cur_score = 0;
-    const uint32_t w = M.ld32(i);
-    if (M.ld32(cand) == w) {
-      AbsMatch m = extend2(M, len, i, cand, S.next_emit);
-      if (m.end - m.start > P.min_length) {
+    AbsMatch m;
+    if (ce & kChainMaybe) {
+      const bool hit = cand_fast ? match_regs(M, len, i, cand, S.next_emit, cf, cf2, cand_fast2, cb, m)
+                                 : match_at(M, len, i, cand, S.next_emit, m);
+      if (hit && m.end - m.start > P.min_length) {
         int64_t sc = score(m, P.distance_bit_cost);
         if (sc > 0) {
           cur = m;
@@ -224,14 +349,13 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       }
     }
     for (int32_t j = 0; j < P.chain_length; j++) {
-      uint32_t dd = M.chain_at(cand);
+      uint32_t dd = M.chain_at(cand) & kChainDelta;
       if (dd == 0) break;
       // Go: candidate -= int(delta) in 64-bit; dd > cand means candidate <= 0
       if (dd >= (uint32_t)cand) break;
       cand -= (int32_t)dd;
       if (i - cand > P.max_distance) break;
-      if (M.ld32(cand) == w) {
-        AbsMatch m = extend2(M, len, i, cand, S.next_emit);
+      if (match_at(M, len, i, cand, S.next_emit, m)) {
         if (m.end - m.start > P.min_length) {
           int64_t sc = score(m, P.distance_bit_cost);
           if (sc > cur_score) {
@@ -243,7 +367,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     }
     // m4.go:183-185
     if (cur.end - cur.start < P.min_length) {
-      i++;
+      i = next_pos(S, P, i);
       continue;
     }
 
@@ -254,7 +378,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       if (cur.start <= S.m1.end) penalty = 0;
     }
     if (cur_score <= score(S.m0, P.distance_bit_cost) + penalty) {
-      i++;
+      i = next_pos(S, P, i);
       continue;
     }
 
@@ -277,7 +401,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
             // m4.go:236-252: look for a closer source for the trimmed match
             int32_t pos = m2.start;
             for (;;) {
-              uint32_t dd = M.chain_at(pos);
+              uint32_t dd = M.chain_at(pos) & kChainDelta;
               if (dd == 0) break;
               if ((int64_t)pos - (int64_t)dd <= (int64_t)m2.match) break;
               pos -= (int32_t)dd;
@@ -294,7 +418,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
           emit(S, m2, sink);
       }
     }
-    i++;
+    i = next_pos(S, P, i);
   }
   S.i = i;
   return false;

@@ -145,15 +145,21 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes) 
 // Launches K1 + K3 for `njobs` jobs whose descriptors are already in d_jobs.
 // On return (stream order) counts[job] holds the job's match count and the
 // records sit in w.rs / w.st as described by w.desc.
-int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t *d_chain, const Job *d_jobs,
-                uint32_t *d_table_io, int njobs, const SpecWork &w, uint32_t *d_counts,
+int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
+                uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, const SpecWork &w, uint32_t *d_counts,
                 uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
   const int pb = part_bits_of(p);
   const int nparts = 1 << (p.table_bits - pb);
   const int groups = (njobs + 7) / 8;
   dim3 g1((unsigned)(groups * 8 * nparts));
+  // check bits kept next to a position in the LDS table (kernels.h, K1): as
+  // many as fit above the largest position.  The persistent table of a
+  // streaming handle stores plain positions, so no check bits there.
+  int posbits = 1;
+  while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
+  const int cb = d_table_io ? 0 : std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
   hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, src_total, d_chain,
-                     d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, 0);
+                     d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0);
   HIP_TRY(hipGetLastError());
   if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st));
   const ParseParams P = parse_params(p);
@@ -354,7 +360,7 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
 
   HIP_TRY(hipMemsetAsync(b->d_errors, 0, 4, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  int rc = launch_find(b->p, d_src, chunk_off[nchunks], b->d_chain, b->d_jobs, nullptr, njobs, b->w, b->d_counts,
+  int rc = launch_find(b->p, d_src, chunk_off[nchunks], (uint32_t)b->max_chunk_bytes, b->d_chain, b->d_jobs, nullptr, njobs, b->w, b->d_counts,
                        b->d_errors, st, b->timing ? b->ev[1] : nullptr);
   if (rc) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -389,7 +395,7 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
   HIP_TRY(hipEventRecord(b->ev[0], nullptr));
   for (int r = 0; r < reps; r++)
     hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), nullptr, d_src, src_total,
-                       b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, dbg);
+                       b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[1], nullptr));
   HIP_TRY(hipEventSynchronize(b->ev[1]));
@@ -760,7 +766,7 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   // positions in [start, len-7) that K1 does not visit keep chain = 0 only if
   // cleared: the last 7 of every block are never inserted (m4.go:112).
   HIP_TRY(hipMemsetAsync(c->d_chain + c->hist_len, 0, n * 4, c->st));
-  rc = launch_find(p, c->d_hist, (uint64_t)c->hist_len + n, c->d_chain, c->d_job, c->d_table, 1, c->w, c->d_counts,
+  rc = launch_find(p, c->d_hist, (uint64_t)c->hist_len + n, (uint32_t)(c->hist_len + (int64_t)n), c->d_chain, c->d_job, c->d_table, 1, c->w, c->d_counts,
                    c->d_counts + 1, c->st, nullptr);
   if (rc) return rc;
   if ((rc = launch_compact(c->w, c->d_job, c->d_counts, 1, c->d_out_off, c->d_out, c->out_cap, c->st)))

@@ -188,7 +188,9 @@ class M4:
         chain = np.zeros(max(n, 1), dtype=np.uint32)
         _check(L.m4g_debug_dump_tables(h, table.ctypes.data, chain.ctypes.data, n),
                "m4g_debug_dump_tables")
-        return table, chain[:n]
+        # bit 31 of a chain entry is the kernels' "4 bytes may match" hint, not part
+        # of the reference's chain value
+        return table, chain[:n] & np.uint32(0x7FFFFFFF)
 
 
 class AutoReset:

@@ -31,7 +31,7 @@ void build_chain(const uint8_t *src, int32_t start, int32_t len, int hash_len, i
     uint64_t h = ((ld64(src + i) & mask) * 0x1E35A7BD1E35A7BDull) >> (64 - table_bits);
     uint32_t c = table[h];
     table[h] = (uint32_t)i;
-    chain[i] = c ? (uint32_t)i - c : 0;
+    chain[i] = c ? (((uint32_t)i - c) | kChainMaybe) : 0;
   }
 }
 } // namespace
