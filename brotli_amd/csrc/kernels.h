@@ -353,9 +353,18 @@ constexpr int K3_THREADS = 64;
 // range are served from LDS (row strides are odd, so lanes at equal offsets
 // hit different banks); reads outside it (match sources, long extensions)
 // still go to global memory.
-constexpr int K3_W = 32;
+#ifndef M4G_K3_W
+#define M4G_K3_W 16
+#endif
+#ifndef M4G_K3_MINWAVES
+#define M4G_K3_MINWAVES 1
+#endif
+constexpr int K3_W = M4G_K3_W;
 constexpr int K3_BACK = 16;
-constexpr int K3_FWD = 32;
+#ifndef M4G_K3_FWD
+#define M4G_K3_FWD 32
+#endif
+constexpr int K3_FWD = M4G_K3_FWD;
 constexpr int K3_SRC_BYTES = K3_BACK + K3_W + K3_FWD;  // 80 = 5 x 16
 constexpr int K3_SRC_PIECES = K3_SRC_BYTES / 16;
 constexpr int K3_SRC_DW = K3_SRC_BYTES / 4 + 1;        // +1: the funnel shift reads one dword ahead
@@ -444,7 +453,7 @@ __device__ __forceinline__ void k3_stage(const uint8_t *__restrict__ src_base, i
   }
 }
 
-__global__ __launch_bounds__(K3_THREADS) void k3a_spec(
+__global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     const uint8_t *__restrict__ src_base, uint64_t src_total,
     const uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, Rec *__restrict__ rs,
     ParseState *__restrict__ E, BlockDesc *__restrict__ desc, uint32_t *__restrict__ errors,

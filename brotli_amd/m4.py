@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm4g.so")
+LIB_PATH = os.environ.get("M4G_LIB") or os.path.join(_HERE, "libm4g.so")
 
 M4G_OK = 0
 ERR_BASE = -1000000
