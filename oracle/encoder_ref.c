@@ -327,6 +327,23 @@ static void store_static_code_length_code(bitwriter *bw) {
   }
 }
 
+/* Test hook: the serialised static code-length code as (bits, nbits); the
+ * reference writes the constant 0x55555554 (32 bits) then 0xFF (8 bits),
+ * entropy_encode_static.go:785-788. */
+uint64_t encref_static_code_length_header(unsigned *nbits) {
+  bitwriter bw;
+  memset(&bw, 0, sizeof(bw));
+  init_cl();
+  /* 40 bits: the first 32 are flushed to dst, 8 stay pending */
+  store_static_code_length_code(&bw);
+  uint64_t v = 0;
+  for (size_t i = 0; i < bw.len; i++) v |= (uint64_t)bw.dst[i] << (8 * i);
+  v |= bw.bits << (8 * bw.len);
+  *nbits = (unsigned)(8 * bw.len) + bw.nbits;
+  free(bw.dst);
+  return v;
+}
+
 /* RFC 7932 section 3.5 repeat codes.  A run of `reps` zeros as a chain of
  * symbol-17 codes (3 extra bits): each further 17 turns the running count c
  * into 8*(c-2) + extra + 3. */

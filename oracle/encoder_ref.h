@@ -53,6 +53,9 @@ uint16_t encref_combine_length_codes(uint16_t inscode, uint16_t copycode,
                                      int use_last_distance);
 encref_distcode encref_distance_code(uint32_t distance);
 
+/* test hook, see encoder_ref.c */
+uint64_t encref_static_code_length_header(unsigned *nbits);
+
 typedef struct encref_encoder encref_encoder;
 encref_encoder *encref_encoder_new(void);
 void encref_encoder_free(encref_encoder *e);

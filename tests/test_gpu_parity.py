@@ -147,3 +147,32 @@ def test_full_size_chunks_properties():
         got = out[o[c]:o[c + 1]]
         assert replay(got, chunk.tobytes()) == chunk.tobytes()
         assert same(got, OracleM4(**PARAMS_G).FindMatches(chunk)), f"chunk {c}"
+
+
+def test_golden_vectors_gpu():
+    """The committed fixtures (tests/golden) through the HIP path."""
+    import os
+    from golden.make_golden import PARAM_SETS, golden_inputs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m4_matches.npz"))
+    for name, data in golden_inputs().items():
+        for pname, kw in PARAM_SETS.items():
+            assert same(m4.M4(**kw).find_matches(data), g[f"m/{pname}/{name}"]), (pname, name)
+    data = synth.text(5 * 16384, 9)
+    h = m4.M4(MaxDistance=12000, ChainLength=2, DistanceBitCost=66)
+    for b in range(5):
+        assert same(h.find_matches(data[b * 16384:(b + 1) * 16384]), g[f"p1/{b}"]), b
+
+
+def test_seeded_repeat_distance_gpu():
+    """FindMatches(dst, src) with a non-empty dst (m4.go:129-130)."""
+    b1 = b"abcdefghijklmnop" * 4 + b"XY"
+    b2 = b"0123" + b"abcdefghijklmnop" * 2 + b"tail-of-the-block"
+    g, o = m4.M4(), OracleM4()
+    dst = g.FindMatches([], b1)
+    m1 = o.FindMatches(b1)
+    assert same(dst, m1)
+    seed = dst[-1][2] if dst[-1][1] else [d for d in dst if d[1]][-1][2]
+    got = g.find_matches(b2, seed)
+    assert same(got, o.FindMatches(b2, seed_prev_distance=seed))
+    with pytest.raises(m4.M4GError):
+        m4.M4().find_matches(b1, 1000)
