@@ -1,0 +1,132 @@
+// m4g_matchfinder.hpp -- C++ mirror of the reference's plugin interface over
+// the C-ABI of m4g.h (header only).  The reference's host language is Go and
+// no Go toolchain exists in the build image, so the host side above the C-ABI
+// is written in C++ with the reference's names and semantics; the Go shim a
+// maintainer would add is in INTEGRATION.md.
+//
+//   matchfinder.Match        matchfinder/matchfinder.go:16-20
+//   matchfinder.MatchFinder  matchfinder/matchfinder.go:23-30
+//   matchfinder.Encoder      matchfinder/matchfinder.go:33-41
+//   matchfinder.M4           matchfinder/m4.go:15-57 (fields, Reset, FindMatches)
+//   matchfinder.AutoReset    matchfinder/textencoder.go:46-53
+//   matchfinder.Writer       matchfinder/matchfinder.go:44-103
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "m4g.h"
+
+namespace matchfinder {
+
+struct Match {
+  int64_t Unmatched = 0, Length = 0, Distance = 0;
+};
+
+struct MatchFinder {
+  virtual ~MatchFinder() = default;
+  // appends to dst and returns it
+  virtual std::vector<Match> &FindMatches(std::vector<Match> &dst, const uint8_t *src, size_t n) = 0;
+  virtual void Reset() = 0;
+};
+
+struct Encoder {
+  virtual ~Encoder() = default;
+  virtual std::vector<uint8_t> &Encode(std::vector<uint8_t> &dst, const uint8_t *src, size_t n,
+                                       const std::vector<Match> &matches, bool lastBlock) = 0;
+  virtual void Reset() = 0;
+};
+
+// matchfinder.M4 running on an MI355X.  Broken invariants panic in the
+// reference (m0.go:50-52); here they throw.
+class M4 : public MatchFinder {
+public:
+  int MaxDistance = 0, MinLength = 0, HashLen = 0, TableBits = 0, ChainLength = 0,
+      DistanceBitCost = 0;
+  int Device = 0;
+
+  ~M4() override { m4g_destroy(ctx_); }
+
+  std::vector<Match> &FindMatches(std::vector<Match> &dst, const uint8_t *src, size_t n) override {
+    if (!ctx_) {
+      m4g_params p{MaxDistance, MinLength, HashLen, TableBits, ChainLength, DistanceBitCost};
+      check(m4g_create(&p, Device, &ctx_), "m4g_create");
+    }
+    const size_t cap = n / (size_t)(MinLength ? MinLength : 4) + 2;
+    if (buf_.size() < cap) buf_.resize(cap);
+    const uint32_t seed = dst.empty() ? 0u : (uint32_t)dst.back().Distance;
+    const int64_t r = m4g_find_matches(ctx_, src, n, seed, buf_.data(), buf_.size());
+    check(r, "m4g_find_matches");
+    dst.reserve(dst.size() + (size_t)r);
+    for (int64_t k = 0; k < r; k++)
+      dst.push_back(Match{buf_[k].unmatched, buf_[k].length, buf_[k].distance});
+    return dst;
+  }
+  void Reset() override {
+    if (ctx_) check(m4g_reset(ctx_), "m4g_reset");
+  }
+
+private:
+  static void check(int64_t rc, const char *what) {
+    if (rc < 0)
+      throw std::runtime_error(std::string(what) + ": " + m4g_strerror((int)rc) + " (" +
+                               m4g_last_error() + ")");
+  }
+  m4g_ctx *ctx_ = nullptr;
+  std::vector<m4g_match> buf_;
+};
+
+struct AutoReset : MatchFinder {
+  MatchFinder *Inner = nullptr;
+  std::vector<Match> &FindMatches(std::vector<Match> &dst, const uint8_t *src, size_t n) override {
+    Inner->Reset();
+    return Inner->FindMatches(dst, src, n);
+  }
+  void Reset() override { Inner->Reset(); }
+};
+
+// Dest is any callable taking (const uint8_t*, size_t).
+template <class Dest> class Writer {
+public:
+  Dest *dest = nullptr;
+  MatchFinder *matchFinder = nullptr;
+  Encoder *encoder = nullptr;
+  size_t BlockSize = 0;
+
+  size_t Write(const uint8_t *p, size_t n) {
+    if (BlockSize == 0) {
+      writeBlock(p, n, false);
+      return n;
+    }
+    inBuf_.insert(inBuf_.end(), p, p + n);
+    size_t pos = 0;
+    for (; pos + BlockSize <= inBuf_.size(); pos += BlockSize)
+      writeBlock(inBuf_.data() + pos, BlockSize, false);
+    if (pos) inBuf_.erase(inBuf_.begin(), inBuf_.begin() + (ptrdiff_t)pos);
+    return n;
+  }
+  void Close() {
+    writeBlock(inBuf_.data(), inBuf_.size(), true);
+    inBuf_.clear();
+  }
+  void Reset(Dest *newDest) {
+    matchFinder->Reset();
+    encoder->Reset();
+    inBuf_.clear();
+    dest = newDest;
+  }
+
+private:
+  void writeBlock(const uint8_t *p, size_t n, bool last) {
+    outBuf_.clear();
+    matches_.clear();
+    matchFinder->FindMatches(matches_, p, n);
+    encoder->Encode(outBuf_, p, n, matches_, last);
+    (*dest)(outBuf_.data(), outBuf_.size());
+  }
+  std::vector<uint8_t> inBuf_, outBuf_;
+  std::vector<Match> matches_;
+};
+
+} // namespace matchfinder

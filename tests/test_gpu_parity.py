@@ -176,3 +176,12 @@ def test_seeded_repeat_distance_gpu():
     assert same(got, o.FindMatches(b2, seed_prev_distance=seed))
     with pytest.raises(m4.M4GError):
         m4.M4().find_matches(b1, 1000)
+
+
+def test_cpp_host_mirror():
+    """include/m4g_matchfinder.hpp: matchfinder::M4 through the C-ABI from C++."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sim", "host_mirror_check")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
