@@ -453,6 +453,20 @@ __device__ __forceinline__ void k3_stage(const uint8_t *__restrict__ src_base, i
   }
 }
 
+// XCD-aware wave placement: workgroups b and b+8 run on the same XCD (observed
+// round-robin dispatch; a speed assumption only).  A job's sub-blocks are
+// spread over kmax/64 consecutive waves; give all of them the same b % 8 so
+// that the job's bytes -- read at random as match sources -- are cached in ONE
+// XCD's L2 instead of being pulled into all eight.
+__device__ __forceinline__ uint64_t k3_wave_of_block(uint32_t b, uint32_t nblocks, uint32_t kmax) {
+  const uint32_t wpj = (kmax + K3_THREADS - 1) / K3_THREADS; // waves per job (when kmax % 64 == 0)
+  const uint32_t group = 8 * wpj;
+  if (kmax % K3_THREADS != 0 || b >= (nblocks / group) * group) return b;
+  const uint32_t g = b / group, r = b % group;
+  const uint32_t xcd = r % 8, slot = r / 8;
+  return (uint64_t)g * group + xcd * wpj + slot;
+}
+
 __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     const uint8_t *__restrict__ src_base, uint64_t src_total,
     const uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, Rec *__restrict__ rs,
@@ -461,7 +475,7 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   __shared__ uint32_t lds_src[K3_THREADS * K3_SRC_DW];
   __shared__ uint32_t lds_ch[K3_THREADS * K3_CH_DW];
   const int lane = threadIdx.x;
-  const uint64_t t = (uint64_t)blockIdx.x * K3_THREADS + lane;
+  const uint64_t t = k3_wave_of_block(blockIdx.x, gridDim.x, L.kmax) * K3_THREADS + lane;
   const uint32_t job = (uint32_t)(t / L.kmax), k = (uint32_t)(t % L.kmax);
   // no early return: every lane takes part in the cooperative staging
   Job J{};
@@ -516,7 +530,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
     const ParseState *__restrict__ E, ParseState *__restrict__ Tout,
     BlockDesc *__restrict__ desc, uint32_t *__restrict__ errors, int njobs, SpecLayout L,
     ParseParams P) {
-  const uint64_t t = (uint64_t)blockIdx.x * K3_THREADS + threadIdx.x;
+  const uint64_t t = k3_wave_of_block(blockIdx.x, gridDim.x, L.kmax) * K3_THREADS + threadIdx.x;
   const uint32_t job = (uint32_t)(t / L.kmax), k = (uint32_t)(t % L.kmax);
   if (job >= (uint32_t)njobs || k == 0) return;
   const Job J = jobs[job];
