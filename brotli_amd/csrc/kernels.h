@@ -46,22 +46,25 @@ constexpr uint64_t kHashMul64 = 0x1E35A7BD1E35A7BDull; // m4.go:285
 //     coalesced 16-byte loads (the next tile is in flight while the current
 //     one is processed); every thread forms its unaligned 8-byte hash windows
 //     from LDS;
-//   * every wave hashes 64*K1_PER positions and compacts the ~1/nparts of
-//     them that fall into this partition into a per-wave LDS queue (ballot +
-//     mbcnt, position order is kept), so the table protocol below runs on
-//     dense lanes;
-//   * consecutive queue entries with equal hash and consecutive positions
-//     ("runs", e.g. zero pages) are folded: the run head stands for the run
-//     and carries its last position, interior positions have chain = 1;
-//   * table protocol per tile (the order of the threads does not matter):
-//         old = T[h];  barrier;  ds_max(T[h], tail);  barrier;  r = T[h]
-//     leaves T as the sequential loop would, and r == tail identifies the
-//     latest run of each hash.  Hashes that occur in more than one run of the
-//     tile are resolved level by level (one barrier each): all runs that lost
-//     against run r ds_max their tail into pred[r]; the largest is r's
-//     predecessor and the root of the next level.  Text needs a few levels
-//     for a few threads per tile; the worst case (period-2 data) is bounded
-//     by the tile size.
+//   * PRODUCE: every wave hashes 64*K1_PER positions; the ~1/nparts of them
+//     that fall into this partition are routed by the next 4 hash bits to one
+//     of 16 OWNER waves (one LDS queue each, appended with ds_add_rtn).
+//     Positions that continue a run of equal hashes (zero pages) are not
+//     queued: their chain entry is 1 and only the run head is queued, with
+//     the run length in a side array;
+//   * CONSUME: wave c owns table slice c and is the only one that touches it.
+//     It sorts its <= 128 queue keys (hash index | position) with a bitonic
+//     network across its lanes.  After the sort equal hashes are adjacent and
+//     in position order, so a key's predecessor is its left neighbour when
+//     the hash is equal and the table entry otherwise; the last key of each
+//     hash updates the table.  Any multiplicity costs the same, and the
+//     workgroup needs two barriers per tile;
+//   * results go back to position order through an LDS array so that the
+//     chain stores of a wave fall into a few cache lines;
+//   * a tile that sends more than K1_QCAP keys to one owner (short-period
+//     data) is redone in slices of 128 positions, which cannot overflow.
+// A table value is  V(p) = p << cb | chk(p):  the position in the high bits
+// and cb check bits of the 4 bytes at p.
 // ---------------------------------------------------------------------------
 constexpr int K1_THREADS = 1024;
 constexpr int K1_WAVES = K1_THREADS / 64;
@@ -69,11 +72,22 @@ constexpr int K1_PER = 3;                              // positions per thread p
 constexpr int K1_SUB = K1_THREADS * K1_PER;            // positions per tile
 constexpr int K1_GROUPS = K1_SUB / 16 + 2;             // 16-byte groups staged per tile (+halo)
 constexpr int K1_TILE_BYTES = K1_GROUPS * 16;
-constexpr int K1_QCAP = 64 * K1_PER;                   // queue entries per wave (worst case)
-constexpr int K1_RELBITS = 12;                         // queue entry = idx << 12 | position in tile
-static_assert(K1_SUB <= (1 << K1_RELBITS), "tile position must fit the queue entry");
-constexpr int K1_MAX_CHECK_BITS = 32 - K1_RELBITS - 15;  // room left in a queue entry
+constexpr int K1_QCAP = 128;                           // keys per owner queue (2 per lane)
+constexpr int K1_MAX_CHECK_BITS = 5;
+// key = index within the owner's slice << 21 | position in tile << 9 | run flag | check bits
+constexpr int K1_KEY_IDX_SHIFT = 21;
+constexpr int K1_KEY_REL_SHIFT = 9;
+constexpr uint32_t K1_KEY_REL_MASK = 0xFFFu;
+constexpr uint32_t K1_KEY_RUN = 0x20u;
+constexpr uint32_t K1_KEY_INVALID = 0xFFFFFFFFu;       // position 4095 >= K1_SUB: never a real key
+static_assert(K1_SUB <= 4095, "tile position must fit the key");
 static_assert(K1_GROUPS <= K1_THREADS, "one 16-byte group per thread");
+
+// dynamic LDS of k1_chain_build (host and device agree through this)
+constexpr size_t k1_lds_bytes(int part_bits) {
+  return ((size_t)1 << part_bits) * 4 + (size_t)K1_TILE_BYTES + (size_t)K1_WAVES * K1_QCAP * 4 +
+         (size_t)K1_SUB * 4 + (size_t)K1_SUB + 2 * K1_WAVES * 4 + (2 + K1_PER) * 4 + 12;
+}
 
 // 8 bytes at byte offset `o` of an LDS byte image (3 aligned dword reads +
 // two funnel shifts; consecutive lanes read consecutive bytes, so the dword
@@ -109,104 +123,87 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Table protocol of one tile for the entries a wave has queued (see the K1
-// header comment).  NJ = entries per lane.  Levels use pred[]: pred[t] collects
-// (ds_max) the tails of the runs that lost against the run whose tail is at
-// tile position t; the largest is that run's predecessor and the next root.
-// A pred slot is used by one hash in one level of one tile, and stale values
-// are positions of earlier tiles (< sb), so pred never needs clearing.
-// A table / pred value is  V(p) = p << cb | chk(p):  the position in the high
-// bits (so ds_max orders by position) and cb check bits of the 4 bytes at p.
+// Bitonic merge steps (partner = lane ^ j for j = JSTART .. 1) of a wave-wide
+// ascending sort, one key per lane.
+template <int JSTART>
+__device__ __forceinline__ uint32_t k1_merge(uint32_t K, uint32_t lane) {
+#pragma unroll
+  for (int j = JSTART; j >= 1; j >>= 1) {
+    const uint32_t p = (uint32_t)__shfl_xor((int)K, j);
+    K = (lane & j) ? max(K, p) : min(K, p);
+  }
+  return K;
+}
+
+// Ascending sort of 64 keys, one per lane (21 compare-exchange steps).
+__device__ __forceinline__ uint32_t k1_sort64(uint32_t K, uint32_t lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+    // first step of each merge pairs lane i with its mirror inside the k-block
+    const uint32_t p = (uint32_t)__shfl((int)K, (int)(lane ^ (uint32_t)(k - 1)));
+    K = (lane & (k >> 1)) ? max(K, p) : min(K, p);
+    if (k == 4) K = k1_merge<1>(K, lane);
+    if (k == 8) K = k1_merge<2>(K, lane);
+    if (k == 16) K = k1_merge<4>(K, lane);
+    if (k == 32) K = k1_merge<8>(K, lane);
+    if (k == 64) K = k1_merge<16>(K, lane);
+  }
+  return K;
+}
+
+// Owner wave: sort NJ*64 keys, link equal hashes, read / update the table
+// slice, leave the chain entries in res[] (indexed by tile position).
 template <int NJ>
-__device__ __forceinline__ void k1_protocol(uint32_t *table, uint32_t *pred, uint32_t *flags,
-                                            const uint32_t *myq, uint32_t n, uint32_t sb,
-                                            uint32_t lane, uint32_t tid, uint32_t &level,
-                                            uint32_t *__restrict__ chain, uint32_t cb, int dbg) {
-  constexpr uint32_t kEntMask = (1u << (K1_RELBITS + 15)) - 1; // idx | rel, without check bits
+__device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const uint8_t *runlen8,
+                                           const uint32_t *myq, uint32_t n, uint32_t sb,
+                                           uint32_t lane, uint32_t cb) {
   const uint32_t cmask = (1u << cb) - 1;
-  uint32_t idx[NJ], pos[NJ], chk[NJ], pchk[NJ], vtail[NJ], old[NJ], root[NJ];
-  bool have[NJ], head[NJ], unplaced[NJ], fresh[NJ];
+  uint32_t K[NJ], V[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     const uint32_t e = j * 64 + lane;
-    have[j] = e < n;
-    const uint32_t ent = have[j] ? myq[e] : 0u;
-    idx[j] = (ent & kEntMask) >> K1_RELBITS;
-    pos[j] = sb + (ent & ((1u << K1_RELBITS) - 1));
-    chk[j] = (ent >> (K1_RELBITS + 15)) & cmask;
-    // run folding: entry continues the previous entry (lane-1) when the hash
-    // is the same and the position is the next one
-    const uint32_t prev = __shfl_up(ent, 1);
-    pchk[j] = (prev >> (K1_RELBITS + 15)) & cmask;
-    const bool same = lane > 0 && have[j] && (ent & kEntMask) == (prev & kEntMask) + 1;
-    const unsigned long long cont = __ballot(same);
-    head[j] = have[j] && !same;
-    uint32_t runlen1 = 0; // run length - 1
-    if (head[j] && lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
-    const uint32_t tchk = __shfl(chk[j], (int)(lane + runlen1)); // check bits of the run's tail
-    vtail[j] = ((pos[j] + runlen1) << cb) | tchk;
-    old[j] = head[j] ? table[idx[j]] : 0u;
+    K[j] = e < n ? myq[e] : K1_KEY_INVALID;
   }
-  if (dbg & 8) return; // profiling aid
-  lds_barrier();
-#pragma unroll
-  for (int j = 0; j < NJ; j++)
-    if (head[j]) atomicMax(&table[idx[j]], vtail[j]);
-  lds_barrier();
-  bool any = false;
+  K[0] = k1_sort64(K[0], lane);
+  if (NJ == 2) {
+    K[1] = k1_sort64(K[1], lane);
+    const uint32_t br = (uint32_t)__shfl((int)K[1], (int)(63 - lane));
+    const uint32_t lo = min(K[0], br), hi = max(K[0], br);
+    K[0] = k1_merge<32>(lo, lane);
+    K[1] = k1_merge<32>(hi, lane);
+  }
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    root[j] = head[j] ? table[idx[j]] : 0u; // latest run of this hash
-    unplaced[j] = head[j] && root[j] != vtail[j];
-    if (unplaced[j]) atomicMax(&pred[(root[j] >> cb) - sb], vtail[j]);
-    fresh[j] = head[j] && !unplaced[j]; // placed, predecessor still pending
-    any |= unplaced[j];
+    const uint32_t rel = (K[j] >> K1_KEY_REL_SHIFT) & K1_KEY_REL_MASK;
+    uint32_t len1 = 0; // run length - 1
+    if (K[j] != K1_KEY_INVALID && (K[j] & K1_KEY_RUN)) len1 = runlen8[rel];
+    V[j] = ((sb + rel + len1) << cb) | (K[j] & cmask);
   }
-  if (__ballot(any) && lane == 0) flags[level % 3] = 1;
-  lds_barrier();
-  while (flags[level % 3] && !(dbg & 4)) { // uniform: some run still has to be placed
-    if (tid == 0) flags[(level + 2) % 3] = 0;
-    level++;
-    any = false;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      if (fresh[j]) { // my predecessor is the best run that competed under me
-        const uint32_t m = pred[(vtail[j] >> cb) - sb];
-        const uint32_t mp = m >> cb;
-        if (mp >= sb && mp != 0 && mp < pos[j]) old[j] = m;
-        fresh[j] = false;
-      }
-      if (unplaced[j]) {
-        const uint32_t m = pred[(root[j] >> cb) - sb];
-        if (m == vtail[j]) {
-          unplaced[j] = false;
-          fresh[j] = true;
-        } else {
-          // slots read at this level and slots written for the next level are
-          // disjoint (each run is placed once), so no barrier in between
-          root[j] = m;
-          atomicMax(&pred[(m >> cb) - sb], vtail[j]);
-          any = true;
-        }
-      }
-    }
-    if (__ballot(any) && lane == 0) flags[level % 3] = 1;
-    lds_barrier();
-  }
-  if (tid == 0) flags[(level + 2) % 3] = 0;
-  level++;
-  if (dbg & 1) return; // profiling aid: no chain stores
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    if (!have[j]) continue;
-    uint32_t c;
-    if (head[j]) {
-      const uint32_t op = old[j] >> cb; // position 0 counts as "empty" (m4.go:152)
-      c = op ? ((pos[j] - op) | ((old[j] & cmask) == chk[j] ? kChainMaybe : 0u)) : 0u;
-    } else { // interior of a run: the predecessor is pos-1
-      c = pos[j] > 1 ? (1u | (pchk[j] == chk[j] ? kChainMaybe : 0u)) : 0u;
+    uint32_t Kp = (uint32_t)__shfl_up((int)K[j], 1), Vp = (uint32_t)__shfl_up((int)V[j], 1);
+    uint32_t Kn = (uint32_t)__shfl_down((int)K[j], 1);
+    if (j == 0) {
+      if (lane == 0) Kp = K1_KEY_INVALID;
+    } else {
+      const uint32_t k63 = (uint32_t)__shfl((int)K[j - 1], 63), v63 = (uint32_t)__shfl((int)V[j - 1], 63);
+      if (lane == 0) Kp = k63, Vp = v63;
     }
-    chain[pos[j]] = c;
+    if (j == NJ - 1) {
+      if (lane == 63) Kn = K1_KEY_INVALID;
+    } else {
+      const uint32_t k0 = (uint32_t)__shfl((int)K[j + 1], 0);
+      if (lane == 63) Kn = k0;
+    }
+    if (K[j] == K1_KEY_INVALID) continue;
+    const uint32_t idxl = K[j] >> K1_KEY_IDX_SHIFT;
+    const uint32_t rel = (K[j] >> K1_KEY_REL_SHIFT) & K1_KEY_REL_MASK;
+    const bool samep = Kp != K1_KEY_INVALID && (Kp >> K1_KEY_IDX_SHIFT) == idxl;
+    const bool tail = Kn == K1_KEY_INVALID || (Kn >> K1_KEY_IDX_SHIFT) != idxl;
+    const uint32_t P = samep ? Vp : slice[idxl];
+    const uint32_t pp = P >> cb, pos = sb + rel; // position 0 counts as "empty" (m4.go:152)
+    res[rel] = pp ? ((pos - pp) | ((P & cmask) == (K[j] & cmask) ? kChainMaybe : 0u)) : 0u;
+    if (tail) slice[idxl] = V[j];
   }
 }
 
@@ -217,10 +214,12 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   extern __shared__ uint32_t lds[];
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
-  uint32_t *tile = lds + part_size;              // K1_TILE_BYTES/4 dwords
-  uint32_t *queues = tile + K1_TILE_BYTES / 4;   // K1_WAVES * K1_QCAP dwords
-  uint32_t *pred = queues + K1_WAVES * K1_QCAP;  // K1_SUB dwords, indexed by tile position
-  uint32_t *flags = pred + K1_SUB;               // 3 rotating level flags + 1 "multi" flag
+  uint32_t *tile = lds + part_size;                 // K1_TILE_BYTES/4 dwords
+  uint32_t *queues = tile + K1_TILE_BYTES / 4;      // K1_WAVES * K1_QCAP keys
+  uint32_t *res = queues + K1_WAVES * K1_QCAP;      // K1_SUB chain entries, by tile position
+  uint8_t *runlen8 = reinterpret_cast<uint8_t *>(res + K1_SUB); // K1_SUB run lengths - 1
+  uint32_t *qn = res + K1_SUB + K1_SUB / 4;         // 2 x K1_WAVES queue fills (by tile parity)
+  uint32_t *ovf = qn + 2 * K1_WAVES;                // overflow flags: 2 by tile parity + K1_PER fallback rows
 
   const int nparts = 1 << (table_bits - part_bits);
   // XCD-aware placement: blocks b and b+8 share an XCD, so give the nparts
@@ -234,13 +233,11 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   const Job J = jobs[job];
   uint32_t *chain = chain_base + J.chain_off;
   const uint32_t tid = threadIdx.x;
-  const uint32_t lane = tid & 63;
-  uint32_t *myq = queues + (tid >> 6) * K1_QCAP;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
 
   for (uint32_t k = tid; k < part_size; k += K1_THREADS)
     table[k] = table_io ? table_io[(q << part_bits) + k] : 0u;
-  for (uint32_t k = tid; k < K1_SUB; k += K1_THREADS) pred[k] = 0;
-  if (tid < 4) flags[tid] = 0;
+  if (tid < 2 * K1_WAVES + 2 + K1_PER) qn[tid] = 0; // fills and overflow flags
 
   // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces:
   // only the upper dword of the low 64 product bits is needed (table_bits <= 24)
@@ -249,7 +246,9 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   const uint32_t mul_lo = (uint32_t)kHashMul64, mul_hi = (uint32_t)(kHashMul64 >> 32);
   const uint32_t shift = 32 - table_bits;
   const uint32_t idx_mask = part_size - 1;
-  const uint32_t cb = (uint32_t)check_bits; // <= 32 - K1_RELBITS - 15 and positions << cb fit 32 bits
+  const uint32_t own_shift = part_bits > 4 ? part_bits - 4 : 0; // slice = 2^own_shift entries
+  const uint32_t own_mask = (1u << own_shift) - 1;
+  const uint32_t cb = (uint32_t)check_bits; // <= K1_MAX_CHECK_BITS and positions << cb fit 32 bits
   const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
 
   // staged tile: bytes [A, A + K1_TILE_BYTES) of the source buffer, where A is
@@ -258,56 +257,117 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     return (int64_t)((J.src_off + base) & ~(uint64_t)15);
   };
   uint4 pre = make_uint4(0, 0, 0, 0);
-  if (J.start < end && tid < K1_GROUPS)
+  if (J.start < end && tid < K1_GROUPS) {
     pre = load_group(src_base, tile_origin(J.start) + 16 * (int64_t)tid, (int64_t)src_total);
+    reinterpret_cast<uint4 *>(tile)[tid] = pre;
+    if (J.start + K1_SUB < end)
+      pre = load_group(src_base, tile_origin(J.start + K1_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
+  }
+  lds_barrier(); // LDS init and the first tile image are in place
 
-  uint32_t level = 0; // running level counter, selects the flag word
+  uint32_t par = 0; // tile parity: selects the qn / ovf set
 #pragma unroll 1
-  for (uint32_t sb = J.start; sb < end; sb += K1_SUB) {
-    lds_barrier(); // previous tile fully consumed (and LDS init done)
-    if (tid < K1_GROUPS) reinterpret_cast<uint4 *>(tile)[tid] = pre;
+  for (uint32_t sb = J.start; sb < end; sb += K1_SUB, par ^= 1) {
     const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
-    if (sb + K1_SUB < end && tid < K1_GROUPS) // prefetch the next tile meanwhile
-      pre = load_group(src_base, tile_origin(sb + K1_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
-    lds_barrier();
+    uint32_t *myqn = qn + par * K1_WAVES;
 
-    // ---- hash K1_PER positions per lane, compact this partition's into myq ----
-    uint32_t n = 0; // wave-uniform
-#pragma unroll
-    for (int k = 0; k < K1_PER; k++) {
-      const uint32_t rel = k * K1_THREADS + tid; // wave covers 64 consecutive positions per k
+    // Hash window k (64 consecutive positions per wave) and queue the run heads
+    // of this partition at their owners.  Returns whether this lane queued one.
+    auto produce = [&](int k, bool store_interior, uint32_t *overflow) -> bool {
+      const uint32_t rel = k * K1_THREADS + tid;
       const uint2 v = lds_ld64(tile, lds_off0 + rel);
       const uint32_t lo = v.x & mask_lo, hi = v.y & mask_hi;
       const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
       const bool in = sb + rel < end && (h >> part_bits) == q;
-      const unsigned long long bal = __ballot(in);
-      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
       // check bits of the first 4 bytes (top bits of a multiplicative hash)
       const uint32_t ck = cb ? (v.x * 0x9E3779B1u) >> (32 - cb) : 0u;
-      if (in) myq[n + below] = (ck << (K1_RELBITS + 15)) | ((h & idx_mask) << K1_RELBITS) | rel;
-      n += (uint32_t)__builtin_popcountll(bal);
-    }
-    // the wave reads back what its own lanes wrote: LDS ops of one wave are
-    // executed in order, only the compiler must not reorder them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // run folding: this position continues the previous one (lane - 1) when
+      // hash and check bits are equal
+      const uint32_t tag = in ? ((h << K1_MAX_CHECK_BITS) | ck) : 0xFFFFFFFFu; // h < 2^24
+      const uint32_t ptag = (uint32_t)__shfl_up((int)tag, 1);
+      const bool same = lane > 0 && in && tag == ptag;
+      const unsigned long long cont = __ballot(same);
+      const bool head = in && !same;
+      if (same && store_interior && !(dbg & 1))
+        chain[sb + rel] = sb + rel > 1 ? (1u | kChainMaybe) : 0u; // predecessor 0 = "empty"
+      if (head) {
+        uint32_t runlen1 = 0; // run length - 1
+        if (lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
+        const uint32_t idx = h & idx_mask, c = idx >> own_shift;
+        uint32_t key = ((idx & own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | ck;
+        if (runlen1) {
+          runlen8[rel] = (uint8_t)runlen1;
+          key |= K1_KEY_RUN;
+        }
+        const uint32_t s = atomicAdd(&myqn[c], 1u);
+        if (s < (uint32_t)K1_QCAP) queues[c * K1_QCAP + s] = key;
+        else *overflow = 1;
+      }
+      return head;
+    };
+    auto consume = [&]() {
+      const uint32_t n = myqn[wave];
+      if (n == 0) return;
+      uint32_t *slice = table + (wave << own_shift);
+      if (n <= 64) k1_consume<1>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb);
+      else k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb);
+    };
 
-    if (dbg & 2) continue; // profiling aid: hashing + compaction only
-    // Dense entries.  A wave normally holds ~64*K1_PER/nparts <= 64 entries,
-    // one per lane; when some wave has more (one partition gets almost
-    // everything, e.g. zero pages) the whole workgroup takes the general
-    // K1_PER-entries-per-lane path.  The choice is workgroup-uniform because
-    // both paths contain barriers.
-    if (n > 64 && lane == 0) flags[3] = 1;
-    lds_barrier();
-    const bool multi = flags[3] != 0;
-    if (!multi)
-      k1_protocol<1>(table, pred, flags, myq, n, sb, lane, tid, level, chain, cb, dbg);
-    else
-      k1_protocol<K1_PER>(table, pred, flags, myq, n, sb, lane, tid, level, chain, cb, dbg);
-    if (multi && tid == 0) flags[3] = 0; // next tile's barrier orders this store
+    uint32_t headmask = 0;
+#pragma unroll
+    for (int k = 0; k < K1_PER; k++) headmask |= (produce(k, true, &ovf[par]) ? 1u : 0u) << k;
+    lds_barrier(); // queues complete
+    if (!(dbg & 2)) {
+      if (!ovf[par]) {
+        consume();
+      } else if (!(dbg & 4)) {
+        // Some owner got more than K1_QCAP keys.  Redo the tile one window row
+        // (1024 positions) at a time; a row that still overflows (short-period
+        // data) is redone in slices of two windows, which hold <= 128 keys in
+        // total and cannot overflow.
+        if (tid < K1_WAVES) myqn[tid] = 0;
+        lds_barrier();
+#pragma unroll 1
+        for (int k = 0; k < K1_PER; k++) {
+          produce(k, false, &ovf[2 + k]);
+          lds_barrier();
+          if (!ovf[2 + k]) {
+            consume();
+            if (lane == 0) myqn[wave] = 0;
+            lds_barrier();
+            continue;
+          }
+          if (tid < K1_WAVES) myqn[tid] = 0;
+          lds_barrier();
+#pragma unroll 1
+          for (uint32_t u = 0; u < (uint32_t)K1_WAVES; u += 2) {
+            if ((wave & ~1u) == u) produce(k, false, &ovf[2 + k]);
+            lds_barrier();
+            consume();
+            if (lane == 0) myqn[wave] = 0;
+            lds_barrier();
+          }
+        }
+      }
+    }
+    // stage the next tile (everybody is done reading the current image) and
+    // start fetching the one after it
+    if (tid < K1_GROUPS && sb + K1_SUB < end) {
+      reinterpret_cast<uint4 *>(tile)[tid] = pre;
+      if (sb + 2 * K1_SUB < end)
+        pre = load_group(src_base, tile_origin(sb + 2 * K1_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
+    }
+    lds_barrier(); // res[] complete, next image staged
+    // this parity's counters are next used two tiles from now
+    if (lane == 0) myqn[wave] = 0;
+    if (tid == 0) {
+      if (ovf[par]) ovf[2] = ovf[3] = ovf[4] = 0; // fallback flags, one per window row
+      ovf[par] = 0;
+    }
+    if (dbg & 1) continue; // profiling aid: no chain stores
+#pragma unroll
+    for (int k = 0; k < K1_PER; k++)
+      if (headmask & (1u << k)) chain[sb + k * K1_THREADS + tid] = res[k * K1_THREADS + tid];
   }
 
   if (table_io) {

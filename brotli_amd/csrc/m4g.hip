@@ -63,9 +63,6 @@ ParseParams parse_params(const Params &p) {
 constexpr int kMaxPartBits = 15; // 2^15 * 4 B = 128 KiB of LDS
 
 int part_bits_of(const Params &p) { return std::min(p.table_bits, kMaxPartBits); }
-size_t k1_lds_bytes(int part_bits) {
-  return ((size_t)1 << part_bits) * 4 + (size_t)K1_TILE_BYTES + (size_t)K1_WAVES * K1_QCAP * 4 + (size_t)K1_SUB * 4 + 64;
-}
 
 int check_device(int device) {
   if (device < 0)
