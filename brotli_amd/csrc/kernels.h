@@ -123,32 +123,76 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Bitonic merge steps (partner = lane ^ j for j = JSTART .. 1) of a wave-wide
-// ascending sort, one key per lane.
-template <int JSTART>
-__device__ __forceinline__ uint32_t k1_merge(uint32_t K, uint32_t lane) {
-#pragma unroll
-  for (int j = JSTART; j >= 1; j >>= 1) {
-    const uint32_t p = (uint32_t)__shfl_xor((int)K, j);
-    K = (lane & j) ? max(K, p) : min(K, p);
-  }
-  return K;
+// ---- wave-wide bitonic sort, one u32 key per lane ---------------------------
+// Compare-exchange steps whose partner lies in the same row of 16 lanes run on
+// DPP operands (no LDS traffic); when the lanes that keep the minimum are whole
+// banks of 4 lanes, a bank-masked min and a bank-masked max do the step in two
+// instructions.  Steps that cross rows use ds_bpermute with byte addresses
+// computed once per kernel (K1SortAddr).  All 64 lanes must be active.
+struct K1SortAddr {
+  int x16, x32, m32, m64; // (lane ^ 16) << 2, (lane ^ 32) << 2, (lane ^ 31) << 2, (lane ^ 63) << 2
+};
+constexpr int kDppQuadXor1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int kDppQuadMirror = 0x1B; // quad_perm:[3,2,1,0]
+constexpr int kDppWaveShl1 = 0x130;  // lane i reads lane i+1
+constexpr int kDppWaveShr1 = 0x138;  // lane i reads lane i-1
+
+// lane i reads lane i-1 / i+1; the first / last lane gets `edge`
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t edge) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, kDppWaveShr1, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v, uint32_t edge) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, kDppWaveShl1, 0xF, 0xF, false);
 }
 
-// Ascending sort of 64 keys, one per lane (21 compare-exchange steps).
-__device__ __forceinline__ uint32_t k1_sort64(uint32_t K, uint32_t lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-    // first step of each merge pairs lane i with its mirror inside the k-block
-    const uint32_t p = (uint32_t)__shfl((int)K, (int)(lane ^ (uint32_t)(k - 1)));
-    K = (lane & (k >> 1)) ? max(K, p) : min(K, p);
-    if (k == 4) K = k1_merge<1>(K, lane);
-    if (k == 8) K = k1_merge<2>(K, lane);
-    if (k == 16) K = k1_merge<4>(K, lane);
-    if (k == 32) K = k1_merge<8>(K, lane);
-    if (k == 64) K = k1_merge<16>(K, lane);
-  }
-  return K;
+template <int CTRL>
+__device__ __forceinline__ uint32_t k1_ce_quad(uint32_t K, bool upper) {
+  const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp((int)K, (int)K, CTRL, 0xF, 0xF, true);
+  return upper ? max(K, p) : min(K, p);
+}
+__device__ __forceinline__ uint32_t k1_ce_far(uint32_t K, int addr, bool upper) {
+  const uint32_t p = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)K);
+  return upper ? max(K, p) : min(K, p);
+}
+// min on the banks of LO_BANKS (partner through LO_CTRL), max on the others.
+// s_nop 1: a DPP operand must not be read within 2 cycles of the VALU write.
+#define K1_CE_BANKED(K, LO_CTRL, LO_BANKS, HI_CTRL, HI_BANKS)                                        \
+  do {                                                                                               \
+    uint32_t n_;                                                                                     \
+    asm("s_nop 1\n\t"                                                                                \
+        "v_min_u32_dpp %0, %1, %1 " LO_CTRL " row_mask:0xf bank_mask:" LO_BANKS "\n\t"               \
+        "v_max_u32_dpp %0, %1, %1 " HI_CTRL " row_mask:0xf bank_mask:" HI_BANKS                      \
+        : "=&v"(n_)                                                                                  \
+        : "v"(K));                                                                                   \
+    K = n_;                                                                                          \
+  } while (0)
+
+// Merge steps lane ^ j for j = JSTART .. 1 (input bitonic in blocks of 2*JSTART).
+template <int JSTART>
+__device__ __forceinline__ uint32_t k1_merge(uint32_t K, uint32_t lane, const K1SortAddr &A) {
+  if (JSTART >= 32) K = k1_ce_far(K, A.x32, lane & 32);
+  if (JSTART >= 16) K = k1_ce_far(K, A.x16, lane & 16);
+  if (JSTART >= 8) K1_CE_BANKED(K, "row_shl:8", "0x3", "row_shr:8", "0xc");
+  if (JSTART >= 4) K1_CE_BANKED(K, "row_shl:4", "0x5", "row_shr:4", "0xa");
+  if (JSTART >= 2) K = k1_ce_quad<kDppQuadXor2>(K, lane & 2);
+  return k1_ce_quad<kDppQuadXor1>(K, lane & 1);
+}
+
+// Ascending sort of 64 keys, one per lane (21 compare-exchange steps).  The
+// first step of each merge pairs a lane with its mirror inside the block.
+__device__ __forceinline__ uint32_t k1_sort64(uint32_t K, uint32_t lane, const K1SortAddr &A) {
+  K = k1_ce_quad<kDppQuadXor1>(K, lane & 1);
+  K = k1_ce_quad<kDppQuadMirror>(K, lane & 2);
+  K = k1_merge<1>(K, lane, A);
+  K1_CE_BANKED(K, "row_half_mirror", "0x5", "row_half_mirror", "0xa");
+  K = k1_merge<2>(K, lane, A);
+  K1_CE_BANKED(K, "row_mirror", "0x3", "row_mirror", "0xc");
+  K = k1_merge<4>(K, lane, A);
+  K = k1_ce_far(K, A.m32, lane & 16);
+  K = k1_merge<8>(K, lane, A);
+  K = k1_ce_far(K, A.m64, lane & 32);
+  return k1_merge<16>(K, lane, A);
 }
 
 // Owner wave: sort NJ*64 keys, link equal hashes, read / update the table
@@ -156,7 +200,7 @@ __device__ __forceinline__ uint32_t k1_sort64(uint32_t K, uint32_t lane) {
 template <int NJ>
 __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const uint8_t *runlen8,
                                            const uint32_t *myq, uint32_t n, uint32_t sb,
-                                           uint32_t lane, uint32_t cb) {
+                                           uint32_t lane, uint32_t cb, const K1SortAddr &A) {
   const uint32_t cmask = (1u << cb) - 1;
   uint32_t K[NJ], V[NJ];
 #pragma unroll
@@ -164,13 +208,13 @@ __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const
     const uint32_t e = j * 64 + lane;
     K[j] = e < n ? myq[e] : K1_KEY_INVALID;
   }
-  K[0] = k1_sort64(K[0], lane);
+  K[0] = k1_sort64(K[0], lane, A);
   if (NJ == 2) {
-    K[1] = k1_sort64(K[1], lane);
-    const uint32_t br = (uint32_t)__shfl((int)K[1], (int)(63 - lane));
+    K[1] = k1_sort64(K[1], lane, A);
+    const uint32_t br = (uint32_t)__builtin_amdgcn_ds_bpermute(A.m64, (int)K[1]); // reversed
     const uint32_t lo = min(K[0], br), hi = max(K[0], br);
-    K[0] = k1_merge<32>(lo, lane);
-    K[1] = k1_merge<32>(hi, lane);
+    K[0] = k1_merge<32>(lo, lane, A);
+    K[1] = k1_merge<32>(hi, lane, A);
   }
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
@@ -181,20 +225,15 @@ __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const
   }
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    uint32_t Kp = (uint32_t)__shfl_up((int)K[j], 1), Vp = (uint32_t)__shfl_up((int)V[j], 1);
-    uint32_t Kn = (uint32_t)__shfl_down((int)K[j], 1);
-    if (j == 0) {
-      if (lane == 0) Kp = K1_KEY_INVALID;
-    } else {
-      const uint32_t k63 = (uint32_t)__shfl((int)K[j - 1], 63), v63 = (uint32_t)__shfl((int)V[j - 1], 63);
-      if (lane == 0) Kp = k63, Vp = v63;
+    // sorted neighbours: left (Kp, Vp) and right (Kn), across the two slots
+    uint32_t ek = K1_KEY_INVALID, ev = 0, en = K1_KEY_INVALID;
+    if (j > 0) {
+      ek = (uint32_t)__builtin_amdgcn_readlane((int)K[j > 0 ? j - 1 : 0], 63);
+      ev = (uint32_t)__builtin_amdgcn_readlane((int)V[j > 0 ? j - 1 : 0], 63);
     }
-    if (j == NJ - 1) {
-      if (lane == 63) Kn = K1_KEY_INVALID;
-    } else {
-      const uint32_t k0 = (uint32_t)__shfl((int)K[j + 1], 0);
-      if (lane == 63) Kn = k0;
-    }
+    if (j < NJ - 1) en = (uint32_t)__builtin_amdgcn_readlane((int)K[j < NJ - 1 ? j + 1 : j], 0);
+    const uint32_t Kp = wave_shr1(K[j], ek), Vp = wave_shr1(V[j], ev);
+    const uint32_t Kn = wave_shl1(K[j], en);
     if (K[j] == K1_KEY_INVALID) continue;
     const uint32_t idxl = K[j] >> K1_KEY_IDX_SHIFT;
     const uint32_t rel = (K[j] >> K1_KEY_REL_SHIFT) & K1_KEY_REL_MASK;
@@ -234,6 +273,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   uint32_t *chain = chain_base + J.chain_off;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
+  const K1SortAddr SA = {(int)((lane ^ 16) << 2), (int)((lane ^ 32) << 2), (int)((lane ^ 31) << 2),
+                         (int)((lane ^ 63) << 2)};
 
   for (uint32_t k = tid; k < part_size; k += K1_THREADS)
     table[k] = table_io ? table_io[(q << part_bits) + k] : 0u;
@@ -284,15 +325,15 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
       // run folding: this position continues the previous one (lane - 1) when
       // hash and check bits are equal
       const uint32_t tag = in ? ((h << K1_MAX_CHECK_BITS) | ck) : 0xFFFFFFFFu; // h < 2^24
-      const uint32_t ptag = (uint32_t)__shfl_up((int)tag, 1);
-      const bool same = lane > 0 && in && tag == ptag;
+      const uint32_t ptag = wave_shr1(tag, 0xFFFFFFFFu);
+      const bool same = in && tag == ptag;
       const unsigned long long cont = __ballot(same);
       const bool head = in && !same;
       if (same && store_interior && !(dbg & 1))
         chain[sb + rel] = sb + rel > 1 ? (1u | kChainMaybe) : 0u; // predecessor 0 = "empty"
       if (head) {
         uint32_t runlen1 = 0; // run length - 1
-        if (lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
+        if (cont != 0 && lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
         const uint32_t idx = h & idx_mask, c = idx >> own_shift;
         uint32_t key = ((idx & own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | ck;
         if (runlen1) {
@@ -309,8 +350,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
       const uint32_t n = myqn[wave];
       if (n == 0) return;
       uint32_t *slice = table + (wave << own_shift);
-      if (n <= 64) k1_consume<1>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb);
-      else k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb);
+      if (n <= 64) k1_consume<1>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA);
+      else k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA);
     };
 
     uint32_t headmask = 0;
