@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "m4_parse.h"
 #include "m4_spec.h"
 
@@ -312,39 +314,56 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
     uint32_t *myqn = qn + par * K1_WAVES;
 
-    // Hash window k (64 consecutive positions per wave) and queue the run heads
-    // of this partition at their owners.  Returns whether this lane queued one.
-    auto produce = [&](int k, bool store_interior, uint32_t *overflow) -> bool {
-      const uint32_t rel = k * K1_THREADS + tid;
-      const uint2 v = lds_ld64(tile, lds_off0 + rel);
-      const uint32_t lo = v.x & mask_lo, hi = v.y & mask_hi;
-      const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
-      const bool in = sb + rel < end && (h >> part_bits) == q;
-      // check bits of the first 4 bytes (top bits of a multiplicative hash)
-      const uint32_t ck = cb ? (v.x * 0x9E3779B1u) >> (32 - cb) : 0u;
-      // run folding: this position continues the previous one (lane - 1) when
-      // hash and check bits are equal
-      const uint32_t tag = in ? ((h << K1_MAX_CHECK_BITS) | ck) : 0xFFFFFFFFu; // h < 2^24
-      const uint32_t ptag = wave_shr1(tag, 0xFFFFFFFFu);
-      const bool same = in && tag == ptag;
-      const unsigned long long cont = __ballot(same);
-      const bool head = in && !same;
-      if (same && store_interior && !(dbg & 1))
-        chain[sb + rel] = sb + rel > 1 ? (1u | kChainMaybe) : 0u; // predecessor 0 = "empty"
-      if (head) {
-        uint32_t runlen1 = 0; // run length - 1
-        if (cont != 0 && lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
-        const uint32_t idx = h & idx_mask, c = idx >> own_shift;
-        uint32_t key = ((idx & own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | ck;
-        if (runlen1) {
-          runlen8[rel] = (uint8_t)runlen1;
-          key |= K1_KEY_RUN;
+    // Hash NW windows (64 consecutive positions per wave each, window row
+    // kfirst + w) and queue the run heads of this partition at their owners.
+    // Written in phases (all loads, all hashes, all queue atomics, all queue
+    // writes) so the LDS round trips of the windows overlap.  Returns a bit
+    // per window: this lane queued a key.
+    auto produce = [&](auto nw_tag, int kfirst, bool store_interior, uint32_t *overflow) -> uint32_t {
+      constexpr int NW = decltype(nw_tag)::value;
+      uint2 v[NW];
+      uint32_t key[NW], own[NW], slot[NW], heads = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) v[w] = lds_ld64(tile, lds_off0 + (kfirst + w) * K1_THREADS + tid);
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        const uint32_t rel = (kfirst + w) * K1_THREADS + tid;
+        const uint32_t lo = v[w].x & mask_lo, hi = v[w].y & mask_hi;
+        const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
+        const bool in = sb + rel < end && (h >> part_bits) == q;
+        // check bits of the first 4 bytes (top bits of a multiplicative hash)
+        const uint32_t ck = cb ? (v[w].x * 0x9E3779B1u) >> (32 - cb) : 0u;
+        // run folding: this position continues the previous one (lane - 1) when
+        // hash and check bits are equal
+        const uint32_t tag = in ? ((h << K1_MAX_CHECK_BITS) | ck) : 0xFFFFFFFFu; // h < 2^24
+        const uint32_t ptag = wave_shr1(tag, 0xFFFFFFFFu);
+        const bool same = in && tag == ptag;
+        const unsigned long long cont = __ballot(same);
+        const uint32_t idx = h & idx_mask;
+        own[w] = idx >> own_shift;
+        key[w] = ((idx & own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | ck;
+        if (in && !same) heads |= 1u << w;
+        if (cont != 0) { // wave-uniform: some run in this window
+          if (same && store_interior && !(dbg & 1))
+            chain[sb + rel] = sb + rel > 1 ? (1u | kChainMaybe) : 0u; // predecessor 0 = "empty"
+          uint32_t runlen1 = 0; // run length - 1
+          if (lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
+          if ((heads >> w & 1) && runlen1) {
+            runlen8[rel] = (uint8_t)runlen1;
+            key[w] |= K1_KEY_RUN;
+          }
         }
-        const uint32_t s = atomicAdd(&myqn[c], 1u);
-        if (s < (uint32_t)K1_QCAP) queues[c * K1_QCAP + s] = key;
-        else *overflow = 1;
       }
-      return head;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (heads >> w & 1) slot[w] = atomicAdd(&myqn[own[w]], 1u);
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (heads >> w & 1) {
+          if (slot[w] < (uint32_t)K1_QCAP) queues[own[w] * K1_QCAP + slot[w]] = key[w];
+          else *overflow = 1;
+        }
+      return heads;
     };
     auto consume = [&]() {
       const uint32_t n = myqn[wave];
@@ -354,9 +373,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
       else k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA);
     };
 
-    uint32_t headmask = 0;
-#pragma unroll
-    for (int k = 0; k < K1_PER; k++) headmask |= (produce(k, true, &ovf[par]) ? 1u : 0u) << k;
+    const uint32_t headmask = produce(std::integral_constant<int, K1_PER>{}, 0, true, &ovf[par]);
     lds_barrier(); // queues complete
     if (!(dbg & 2)) {
       if (!ovf[par]) {
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
         lds_barrier();
 #pragma unroll 1
         for (int k = 0; k < K1_PER; k++) {
-          produce(k, false, &ovf[2 + k]);
+          produce(std::integral_constant<int, 1>{}, k, false, &ovf[2 + k]);
           lds_barrier();
           if (!ovf[2 + k]) {
             consume();
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
           lds_barrier();
 #pragma unroll 1
           for (uint32_t u = 0; u < (uint32_t)K1_WAVES; u += 2) {
-            if ((wave & ~1u) == u) produce(k, false, &ovf[2 + k]);
+            if ((wave & ~1u) == u) produce(std::integral_constant<int, 1>{}, k, false, &ovf[2 + k]);
             lds_barrier();
             consume();
             if (lane == 0) myqn[wave] = 0;
