@@ -818,9 +818,12 @@ __global__ __launch_bounds__(K4_THREADS) void k4_compact(
 // (sum of Unmatched+Length) and (b) the ring of the last four distances.
 // (a) is a prefix sum.  (b): a distance is pushed exactly when it differs from
 // the previous match's distance, so the ring seen by
-// match j is the last four "flagged" matches before j; a max-scan gives every
-// match the index of the latest flagged match before it (pf[]), and four hops
-// along pf[] rebuild the ring with no serial dependence between matches.
+// match j is the last four "flagged" matches before j.  Inside a wave those
+// are the top set bits of the flag ballot below the lane (distances fetched
+// with cross-lane reads); what is missing comes from the flagged tails of the
+// earlier waves of the iteration and from a carried ring, so one workgroup
+// barrier per 256 matches suffices and no match reads another match's record
+// from memory.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t log2_floor_nz(uint32_t n) { return 31u - __builtin_clz(n); }
 
@@ -866,15 +869,44 @@ __device__ __forceinline__ uint32_t distance_symbol(uint32_t distance) {
 constexpr int K5_THREADS = 256;
 constexpr int K5_WAVES = K5_THREADS / 64;
 
+// Up to four most recent flagged distances, most recent first.
+struct K5Ring {
+  uint32_t d[4];
+  uint32_t n;
+};
+// ring of (newer ++ older), truncated to four
+__device__ __forceinline__ K5Ring k5_ring_cat(const K5Ring &newer, const K5Ring &older) {
+  K5Ring r;
+  r.n = min(4u, newer.n + older.n);
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if ((uint32_t)t < newer.n) {
+        if (u == t) v = newer.d[u];
+      } else if ((uint32_t)(t - (int)newer.n) == (uint32_t)u) {
+        v = older.d[u];
+      }
+    }
+    r.d[t] = v;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ matches /* 3 words each */,
     const Job *__restrict__ jobs, const uint64_t *__restrict__ out_off, uint64_t out_cap,
-    uint32_t *__restrict__ pf_base, uint32_t *__restrict__ histos /* 1024 u32 per job */) {
+    uint32_t *__restrict__ histos /* 1024 u32 per job */) {
   __shared__ uint32_t lit[K5_WAVES][256];
   __shared__ uint32_t cmd[704];
   __shared__ uint32_t dst[64];
-  __shared__ uint32_t wred[K5_WAVES];
-  __shared__ uint32_t carry_s;
+  // per-wave summaries and carries, double buffered by iteration parity so one
+  // barrier per iteration orders everything
+  __shared__ uint32_t wadv[2][K5_WAVES];
+  __shared__ K5Ring wring[2][K5_WAVES];
+  __shared__ uint32_t cpos[2];
+  __shared__ K5Ring cring[2];
 
   const uint32_t job = blockIdx.x;
   const Job J = jobs[job];
@@ -887,46 +919,20 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
   }
   const uint32_t n = (uint32_t)(o1 - o0);
   const uint32_t *rec = matches + o0 * 3;
-  uint32_t *pf = pf_base + o0;
   const uint8_t *src = src_base + J.src_off;
 
   for (int k = tid; k < K5_WAVES * 256; k += K5_THREADS) (&lit[0][0])[k] = 0;
   for (int k = tid; k < 704; k += K5_THREADS) cmd[k] = 0;
   if (tid < 64) dst[tid] = 0;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-
-  // pass 1: pf[j] = 1 + index of the latest flagged match before j (0: none)
-  for (uint32_t base = 0; base < n; base += K5_THREADS) {
-    const uint32_t j = base + tid;
-    uint32_t flag = 0;
-    if (j < n && rec[3 * j + 1] != 0) {
-      uint32_t prevd = j ? rec[3 * j - 1] : 0xFFFFFFFFu;
-      flag = (rec[3 * j + 2] != prevd) ? j + 1 : 0;
-    }
-    uint32_t incl = flag;
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t t = __shfl_up(incl, o);
-      if (lane >= o) incl = max(incl, t);
-    }
-    if (lane == 63) wred[wid] = incl;
-    __syncthreads();
-    uint32_t before = carry_s;
-    for (int w = 0; w < wid; w++) before = max(before, wred[w]);
-    uint32_t excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 0;
-    excl = max(excl, before);
-    if (j < n) pf[j] = excl;
-    __syncthreads();
-    if (tid == K5_THREADS - 1) carry_s = max(before, incl);
-    __syncthreads();
+  if (tid == 0) {
+    cpos[0] = J.start; // input position of the first match's literals
+    cring[0].n = 0;
   }
-  if (tid == 0) carry_s = J.start; // pass 2 carry: input position of the next match
   __syncthreads();
 
-  // pass 2: positions, command + distance symbols, literal histogram
   uint32_t *mylit = lit[wid];
-  for (uint32_t base = 0; base < n; base += K5_THREADS) {
+  uint32_t par = 0;
+  for (uint32_t base = 0; base < n; base += K5_THREADS, par ^= 1) {
     const uint32_t j = base + tid;
     uint32_t un = 0, len = 0, dist = 0;
     if (j < n) {
@@ -934,38 +940,75 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
       len = rec[3 * j + 1];
       dist = rec[3 * j + 2];
     }
-    // exclusive prefix sum of (un + len) = where this match's literals start
-    uint32_t adv = un + len, incl = adv;
+    // distance of the previous match (none before the first)
+    uint32_t prevd = __shfl_up(dist, 1);
+    if (lane == 0) prevd = (j > 0 && j < n) ? rec[3 * j - 1] : 0xFFFFFFFFu;
+    const bool flag = j < n && len != 0 && dist != prevd;
+    const bool use_last = j < n && dist == prevd;
+
+    // inclusive prefix sum of (un + len) inside the wave
+    const uint32_t adv = un + len;
+    uint32_t incl = adv;
     for (int o = 1; o < 64; o <<= 1) {
       uint32_t t = __shfl_up(incl, o);
       if (lane >= o) incl += t;
     }
-    if (lane == 63) wred[wid] = incl;
+    // this wave's flagged distances: the top set bits of the ballot
+    const unsigned long long F = __ballot(flag);
+    K5Ring mine;
+    {
+      unsigned long long f = F;
+      mine.n = min(4u, (uint32_t)__builtin_popcountll(F));
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int l = f ? 63 - __builtin_clzll(f) : 0;
+        mine.d[t] = __shfl(dist, l);
+        f &= ~(1ull << l);
+      }
+    }
+    if (lane == 63) wadv[par][wid] = incl;
+    if (lane == 0) wring[par][wid] = mine;
     __syncthreads();
-    uint32_t before = carry_s;
-    for (int w = 0; w < wid; w++) before += wred[w];
+
+    // carries from the earlier iterations and the earlier waves of this one
+    uint32_t before = cpos[par];
+    K5Ring R = cring[par];
+    for (int w = 0; w < wid; w++) {
+      before += wadv[par][w];
+      R = k5_ring_cat(wring[par][w], R);
+    }
     const uint32_t ls = before + incl - adv;
-    __syncthreads();
-    if (tid == K5_THREADS - 1) carry_s = before + incl;
+    if (tid == K5_THREADS - 1) {
+      cpos[par ^ 1] = before + incl;
+      cring[par ^ 1] = k5_ring_cat(mine, R);
+    }
+
+    // ring seen by this lane: flagged lanes below it, then R.  -10 = none.
+    int64_t ring[4];
+    {
+      unsigned long long f = F & ((1ull << lane) - 1);
+      const uint32_t c = (uint32_t)__builtin_popcountll(f);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int l = f ? 63 - __builtin_clzll(f) : 0;
+        const uint32_t dv = __shfl(dist, l);
+        f &= ~(1ull << l);
+        if ((uint32_t)t < c) {
+          ring[t] = (int64_t)dv;
+        } else {
+          const uint32_t u = (uint32_t)t - c;
+          ring[t] = u < R.n ? (int64_t)(u == 0 ? R.d[0] : u == 1 ? R.d[1] : u == 2 ? R.d[2] : R.d[3])
+                            : -10;
+        }
+      }
+    }
 
     if (j < n) {
       uint32_t ic = insert_length_code(un);
       uint32_t cc = len ? copy_length_code(len) : 2u;
-      bool use_last = j > 0 && dist == rec[3 * j - 1];
       uint32_t command = combine_length_codes(ic, cc, use_last);
       atomicAdd(&cmd[command], 1u);
       if (command >= 128 && len != 0) {
-        // ring d[3], d[2], d[1], d[0] = last four pushed distances (-10: none)
-        int64_t ring[4];
-        uint32_t p = pf[j];
-        for (int t = 0; t < 4; t++) {
-          if (p) {
-            ring[t] = (int64_t)rec[3 * (p - 1) + 2];
-            p = pf[p - 1];
-          } else {
-            ring[t] = -10;
-          }
-        }
         const int64_t D = dist, d3 = ring[0];
         uint32_t code;
         if (D == d3) code = 0;
@@ -982,10 +1025,20 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
         atomicAdd(&dst[code], 1u);
       }
     }
-    // literals: short runs per lane, long runs by the whole wave
+    // literals: short runs per lane (8 bytes per load), long runs by the whole wave
     const bool longrun = un >= 64;
-    if (!longrun)
-      for (uint32_t k = 0; k < un; k++) atomicAdd(&mylit[src[ls + k]], 1u);
+    if (!longrun) {
+      for (uint32_t k = 0; k < un; k += 8) {
+        const uint32_t m = min(un - k, 8u);
+        if (ls + k + 8 <= J.len) {
+          uint64_t w;
+          __builtin_memcpy(&w, src + ls + k, 8);
+          for (uint32_t b = 0; b < m; b++, w >>= 8) atomicAdd(&mylit[w & 0xFF], 1u);
+        } else {
+          for (uint32_t b = 0; b < m; b++) atomicAdd(&mylit[src[ls + k + b]], 1u);
+        }
+      }
+    }
     unsigned long long lm = __ballot(longrun);
     while (lm) {
       int l = __builtin_ctzll(lm);
@@ -993,7 +1046,6 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
       uint32_t u = __shfl(un, l), s0 = __shfl(ls, l);
       for (uint32_t k = lane; k < u; k += 64) atomicAdd(&mylit[src[s0 + k]], 1u);
     }
-    __syncthreads();
   }
   __syncthreads();
 

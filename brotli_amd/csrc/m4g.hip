@@ -236,10 +236,9 @@ extern "C" void m4g_host_free(void *p) {
 struct m4g_batch {
   int device = 0;
   Params p{};
-  size_t max_chunks = 0, max_chunk_bytes = 0, pf_cap = 0;
+  size_t max_chunks = 0, max_chunk_bytes = 0;
   uint32_t *d_chain = nullptr;
   SpecWork w;
-  uint32_t *d_pf = nullptr;
   uint32_t *d_counts = nullptr;
   uint32_t *d_errors = nullptr;
   Job *d_jobs = nullptr;
@@ -254,7 +253,6 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipSetDevice(b->device);
   (void)hipFree(b->d_chain);
   spec_free(b->w);
-  (void)hipFree(b->d_pf);
   (void)hipFree(b->d_counts);
   (void)hipFree(b->d_errors);
   (void)hipFree(b->d_jobs);
@@ -283,7 +281,6 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   b->p = p;
   b->max_chunks = max_chunks;
   b->max_chunk_bytes = max_chunk_bytes;
-  b->pf_cap = max_chunks * (max_chunk_bytes / (size_t)p.min_length + 2);
   const size_t nbytes = max_chunks * max_chunk_bytes;
   if ((rc = spec_alloc(b->w, p, max_chunks, max_chunk_bytes))) {
     m4g_batch_destroy(b);
@@ -291,7 +288,6 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   }
   hipError_t e;
   if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 4096)) != hipSuccess ||
-      (e = hipMalloc(&b->d_pf, b->pf_cap * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_counts, max_chunks * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_errors, 64)) != hipSuccess ||
       (e = hipMalloc(&b->d_jobs, max_chunks * sizeof(Job))) != hipSuccess) {
@@ -369,7 +365,7 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
     static_assert(sizeof(m4g_histo) == 1024 * 4, "m4g_histo layout");
     hipLaunchKernelGGL(k5_histograms, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
                        reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
-                       (uint64_t)std::min(out_cap, b->pf_cap), b->d_pf,
+                       (uint64_t)out_cap,
                        reinterpret_cast<uint32_t *>(d_histos));
     HIP_TRY(hipGetLastError());
   }

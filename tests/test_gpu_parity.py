@@ -127,6 +127,27 @@ def test_batch_host_api_ragged():
             and (histos[c, 960:] == dist).all()
 
 
+@pytest.mark.parametrize("kw", [PARAMS_G, PARAMS_D], ids=["G", "D"])
+def test_batch_histograms_edge_inputs(kw):
+    """Every edge input as one chunk of a ragged batch: match lists and the
+    three histograms of encoder.go:44-105 (rings shorter than four distances,
+    repeated distances, literal runs longer than a wave, empty chunks)."""
+    inputs = edge_inputs()
+    names = sorted(inputs)
+    sizes = [len(inputs[k]) for k in names]
+    blob = b"".join(inputs[k] for k in names)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    out, out_off, histos = m4.find_matches_batch(blob, off, (0,), True, **kw)
+    for c, name in enumerate(names):
+        chunk = inputs[name]
+        ref = OracleM4(**kw).FindMatches(chunk)
+        assert same(out[int(out_off[c]):int(out_off[c + 1])], ref), name
+        lit, cmd, dist, _, _ = histograms(chunk, ref)
+        assert (histos[c, :256] == lit).all(), f"{name}: literal histogram"
+        assert (histos[c, 256:960] == cmd).all(), f"{name}: command histogram"
+        assert (histos[c, 960:] == dist).all(), f"{name}: distance histogram"
+
+
 def test_full_size_chunks_properties():
     """BASELINE config 2 shape (1 MiB chunks, params G): size-independent
     properties on every chunk + bit-exactness on a sample."""
