@@ -27,47 +27,44 @@ struct Job {
   uint32_t start;     // first position to insert / parse (e.NextEmit at entry)
   uint32_t len;       // buffer length (positions [start, len-7) are inserted)
   uint32_t seed_prev; // Distance of the caller's last dst element, 0 = none
-  uint32_t dump_rel;  // element offset (from chain_off) of 16 spare chain slots nobody reads
+  uint32_t pad;
 };
 
 constexpr uint64_t kHashMul64 = 0x1E35A7BD1E35A7BDull; // m4.go:285
 
 // ---------------------------------------------------------------------------
-// K0 + K1: chain build.
+// K1: chain build.
 //
 // chain[i] = i - table[h(i)] (0 when the table entry is empty), table[h(i)] = i,
 // for i = start .. len-8 in order.  "table[h] before the insertion of i" is
 // the largest already inserted position with the same hash, i.e. a pure
 // function of the bytes, so the sequential table of the reference becomes:
-//
-//   K0 k0_hash_route (no table, fully parallel over tiles of K1_SUB positions)
-//     * stages the tile through LDS with coalesced 16-byte loads, every thread
-//       forms its unaligned 8-byte hash windows from LDS and hashes K1_PER
-//       positions -- every position is hashed exactly once;
-//     * positions that continue a run of equal hashes (zero pages) get their
-//       chain entry (1) right here; of a run only its head and its tail are
-//       passed on;
-//     * keys (hash index | position | check bits) are routed by the top hash
-//       bits into one LIST per (table partition, owner wave) -- LDS queues
-//       filled with ds_add_rtn, then flushed to global memory as dense rows of
-//       K1_QCAP keys plus a fill count.
-//
-//   K1 k1_chain_build (one workgroup per (job, table partition), table in LDS)
-//     * the table is split by the top hash bits into partitions of 2^15
-//       entries (128 KiB of the 160 KiB LDS); the partition workgroups of a job
-//       share blockIdx % 8, i.e. one XCD;
-//     * wave c owns table slice c and is the only one that touches it.  Per
-//       tile it loads its list (prefetched one tile ahead), sorts the <= 128
-//       keys with a bitonic network across its lanes -- equal hashes become
-//       adjacent and position ordered, so a key's predecessor is its left
-//       neighbour when the hash is equal and the table entry otherwise; the
-//       last key of each hash updates the table.  Any multiplicity costs the
-//       same and the waves of a workgroup never wait for each other;
-//     * a tile in which some list of the partition overflowed (short-period
-//       data), or every tile when K0 did not run (more than 8 partitions), is
-//       redone by the workgroup itself from the source bytes, one window row
-//       (1024 positions) or, if that still overflows, two windows (128
-//       positions, cannot overflow) at a time.
+//   * the table lives in LDS, split by the top hash bits into `nparts`
+//     partitions of 2^part_bits entries (2^15 * 4 B = 128 KiB of the 160 KiB
+//     LDS); one workgroup owns one (job, partition) and streams the whole
+//     buffer region, so the 4 partition workgroups of a job are placed on one
+//     XCD (blockIdx % 8 equal) and share its L2 for the input bytes;
+//   * the input is staged through LDS in tiles of K1_SUB positions with
+//     coalesced 16-byte loads (the next tile is in flight while the current
+//     one is processed); every thread forms its unaligned 8-byte hash windows
+//     from LDS;
+//   * PRODUCE: every wave hashes 64*K1_PER positions; the ~1/nparts of them
+//     that fall into this partition are routed by the next 4 hash bits to one
+//     of 16 OWNER waves (one LDS queue each, appended with ds_add_rtn).
+//     Positions that continue a run of equal hashes (zero pages) are not
+//     queued: their chain entry is 1 and only the run head is queued, with
+//     the run length in a side array;
+//   * CONSUME: wave c owns table slice c and is the only one that touches it.
+//     It sorts its <= 128 queue keys (hash index | position) with a bitonic
+//     network across its lanes.  After the sort equal hashes are adjacent and
+//     in position order, so a key's predecessor is its left neighbour when
+//     the hash is equal and the table entry otherwise; the last key of each
+//     hash updates the table.  Any multiplicity costs the same, and the
+//     workgroup needs two barriers per tile;
+//   * results go back to position order through an LDS array so that the
+//     chain stores of a wave fall into a few cache lines;
+//   * a tile that sends more than K1_QCAP keys to one owner (short-period
+//     data) is redone in slices of 128 positions, which cannot overflow.
 // A table value is  V(p) = p << cb | chk(p):  the position in the high bits
 // and cb check bits of the 4 bytes at p.
 // ---------------------------------------------------------------------------
@@ -77,29 +74,22 @@ constexpr int K1_PER = 3;                              // positions per thread p
 constexpr int K1_SUB = K1_THREADS * K1_PER;            // positions per tile
 constexpr int K1_GROUPS = K1_SUB / 16 + 2;             // 16-byte groups staged per tile (+halo)
 constexpr int K1_TILE_BYTES = K1_GROUPS * 16;
-constexpr int K1_QCAP = 256;                           // keys per list (up to 4 per lane)
-constexpr int K1_FQCAP = 128;                          // keys per owner queue when K1 redoes a tile itself
-constexpr uint32_t K1_RES_EMPTY = 0xFFFFFFFFu;         // res[] slot without a chain entry (never a real value)
+constexpr int K1_QCAP = 128;                           // keys per owner queue (2 per lane)
 constexpr int K1_MAX_CHECK_BITS = 5;
-constexpr int K1_MAX_LISTS = 128;                      // K0 runs for up to 8 partitions x 16 owners
-// key = index within the owner's slice << 21 | position in tile << 9 | run tail flag | check bits
+// key = index within the owner's slice << 21 | position in tile << 9 | run flag | check bits
 constexpr int K1_KEY_IDX_SHIFT = 21;
 constexpr int K1_KEY_REL_SHIFT = 9;
 constexpr uint32_t K1_KEY_REL_MASK = 0xFFFu;
-constexpr uint32_t K1_KEY_TAIL = 0x20u;                // last position of a run: chain entry already stored
+constexpr uint32_t K1_KEY_RUN = 0x20u;
 constexpr uint32_t K1_KEY_INVALID = 0xFFFFFFFFu;       // position 4095 >= K1_SUB: never a real key
 static_assert(K1_SUB <= 4095, "tile position must fit the key");
 static_assert(K1_GROUPS <= K1_THREADS, "one 16-byte group per thread");
-static_assert(K1_PER == 3, "fallback flags are laid out for three window rows");
 
-// dynamic LDS of the two kernels (host and device agree through these)
-constexpr size_t k0_lds_bytes(int nlists) {
-  return (size_t)K1_TILE_BYTES + (size_t)nlists * K1_QCAP * 4 + 2 * (size_t)nlists * 4;
-}
+// dynamic LDS of k1_chain_build (host and device agree through this)
 constexpr size_t k1_lds_bytes(int part_bits) {
-  return ((size_t)1 << part_bits) * 4 + 2 * (size_t)K1_SUB * 4 + (size_t)K1_WAVES * 4 + (1 + K1_PER) * 4 + 16;
+  return ((size_t)1 << part_bits) * 4 + (size_t)K1_TILE_BYTES + (size_t)K1_WAVES * K1_QCAP * 4 +
+         (size_t)K1_SUB * 4 + (size_t)K1_SUB + 2 * K1_WAVES * 4 + (2 + K1_PER) * 4 + 12;
 }
-static_assert(K1_TILE_BYTES / 4 + K1_WAVES * K1_FQCAP <= K1_SUB, "fallback scratch must fit one res[] buffer");
 
 // 8 bytes at byte offset `o` of an LDS byte image (3 aligned dword reads +
 // two funnel shifts; consecutive lanes read consecutive bytes, so the dword
@@ -128,8 +118,8 @@ __device__ __forceinline__ uint4 load_group(const uint8_t *src_base, int64_t g, 
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits
-// for vmcnt(0), which would expose the latency of global stores and of the
-// next tile's prefetch at every barrier.  Nothing here communicates through
+// for vmcnt(0), which would expose the latency of the chain stores and of the
+// next tile's prefetch at every barrier.  Nothing in K1 communicates through
 // global memory inside a launch, so LDS ordering is all the barrier must give.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -207,105 +197,37 @@ __device__ __forceinline__ uint32_t k1_sort64(uint32_t K, uint32_t lane, const K
   return k1_merge<16>(K, lane, A);
 }
 
-// Hash geometry shared by K0 and K1.
-struct K1Hash {
-  uint32_t mask_lo, mask_hi, mul_lo, mul_hi, shift;
-  uint32_t part_bits, own_shift, own_mask, idx_mask, cb;
-  __device__ __forceinline__ void init(int hash_len, int table_bits, int part_bits_, int check_bits) {
-    // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces:
-    // only the upper dword of the low 64 product bits is needed (table_bits <= 24)
-    const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
-    mask_lo = (uint32_t)mask;
-    mask_hi = (uint32_t)(mask >> 32);
-    mul_lo = (uint32_t)kHashMul64;
-    mul_hi = (uint32_t)(kHashMul64 >> 32);
-    shift = 32 - table_bits;
-    part_bits = (uint32_t)part_bits_;
-    own_shift = part_bits > 4 ? part_bits - 4 : 0; // an owner's slice = 2^own_shift entries
-    own_mask = (1u << own_shift) - 1;
-    idx_mask = (1u << part_bits) - 1;
-    cb = (uint32_t)check_bits; // <= K1_MAX_CHECK_BITS and positions << cb fit 32 bits
-  }
-  __device__ __forceinline__ uint32_t hash(uint2 v) const {
-    const uint32_t lo = v.x & mask_lo, hi = v.y & mask_hi;
-    return (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
-  }
-  // check bits of the first 4 bytes (top bits of a multiplicative hash)
-  __device__ __forceinline__ uint32_t check(uint2 v) const {
-    return cb ? (v.x * 0x9E3779B1u) >> (32 - cb) : 0u;
-  }
-};
-
-// One window (64 consecutive positions, one per lane) of run folding.
-//   in    this lane's position takes part (in range, and in the partition)
-//   h     its table index incl. partition bits, ck its check bits
-// A position continues a run when the previous position (lane - 1) has the
-// same hash and check bits; its chain entry is 1 and is stored here.  Returns
-// whether the lane must queue a key (run heads, run tails, single positions)
-// and the key's flag bits.
-__device__ __forceinline__ bool k1_fold_window(bool in, uint32_t h, uint32_t ck, uint32_t pos,
-                                               uint32_t *__restrict__ chain, bool store,
-                                               uint32_t &flags) {
-  const uint32_t tag = in ? ((h << K1_MAX_CHECK_BITS) | ck) : 0xFFFFFFFFu; // h < 2^24
-  const uint32_t ptag = wave_shr1(tag, 0xFFFFFFFFu);
-  const bool same = in && tag == ptag;
-  flags = 0;
-  if (__ballot(same) == 0) return in; // wave-uniform: no run in this window
-  const bool next_same = wave_shl1(same ? 1u : 0u, 0u) != 0;
-  if (same) {
-    if (store) chain[pos] = pos > 1 ? (1u | kChainMaybe) : 0u; // predecessor 0 = "empty" (m4.go:152)
-    flags = K1_KEY_TAIL;
-  }
-  return in && (!same || !next_same);
-}
-
-// Sorted a, b (ascending, one key per lane each) -> the 128 keys sorted over (a, b).
-__device__ __forceinline__ void k1_sort128(uint32_t &a, uint32_t &b, uint32_t lane, const K1SortAddr &A) {
-  a = k1_sort64(a, lane, A);
-  b = k1_sort64(b, lane, A);
-  const uint32_t br = (uint32_t)__builtin_amdgcn_ds_bpermute(A.m64, (int)b); // reversed
-  const uint32_t lo = min(a, br), hi = max(a, br);
-  a = k1_merge<32>(lo, lane, A);
-  b = k1_merge<32>(hi, lane, A);
-}
-// (a, b) bitonic over 128 keys -> sorted.
-__device__ __forceinline__ void k1_merge128(uint32_t &a, uint32_t &b, uint32_t lane, const K1SortAddr &A) {
-  const uint32_t lo = min(a, b), hi = max(a, b);
-  a = k1_merge<32>(lo, lane, A);
-  b = k1_merge<32>(hi, lane, A);
-}
-
 // Owner wave: sort NJ*64 keys, link equal hashes, read / update the table
 // slice, leave the chain entries in res[] (indexed by tile position).
 template <int NJ>
-__device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, uint32_t (&K)[NJ],
-                                           uint32_t sb, uint32_t lane, uint32_t cb,
-                                           const K1SortAddr &A) {
-  static_assert(NJ == 1 || NJ == 2 || NJ == 4, "1, 2 or 4 keys per lane");
+__device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const uint8_t *runlen8,
+                                           const uint32_t *myq, uint32_t n, uint32_t sb,
+                                           uint32_t lane, uint32_t cb, const K1SortAddr &A) {
   const uint32_t cmask = (1u << cb) - 1;
-  uint32_t V[NJ];
-  if (NJ == 1) K[0] = k1_sort64(K[0], lane, A);
-  if (NJ >= 2) k1_sort128(K[0], K[1], lane, A);
-  if (NJ == 4) {
-    k1_sort128(K[2], K[3], lane, A);
-    const uint32_t r3 = (uint32_t)__builtin_amdgcn_ds_bpermute(A.m64, (int)K[3]);
-    const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute(A.m64, (int)K[2]);
-    uint32_t lo0 = min(K[0], r3), hi0 = max(K[0], r3), lo1 = min(K[1], r2), hi1 = max(K[1], r2);
-    k1_merge128(lo0, lo1, lane, A);
-    k1_merge128(hi0, hi1, lane, A);
-    K[0] = lo0;
-    K[1] = lo1;
-    K[2] = hi0;
-    K[3] = hi1;
+  uint32_t K[NJ], V[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const uint32_t e = j * 64 + lane;
+    K[j] = e < n ? myq[e] : K1_KEY_INVALID;
+  }
+  K[0] = k1_sort64(K[0], lane, A);
+  if (NJ == 2) {
+    K[1] = k1_sort64(K[1], lane, A);
+    const uint32_t br = (uint32_t)__builtin_amdgcn_ds_bpermute(A.m64, (int)K[1]); // reversed
+    const uint32_t lo = min(K[0], br), hi = max(K[0], br);
+    K[0] = k1_merge<32>(lo, lane, A);
+    K[1] = k1_merge<32>(hi, lane, A);
   }
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     const uint32_t rel = (K[j] >> K1_KEY_REL_SHIFT) & K1_KEY_REL_MASK;
-    V[j] = ((sb + rel) << cb) | (K[j] & cmask);
+    uint32_t len1 = 0; // run length - 1
+    if (K[j] != K1_KEY_INVALID && (K[j] & K1_KEY_RUN)) len1 = runlen8[rel];
+    V[j] = ((sb + rel + len1) << cb) | (K[j] & cmask);
   }
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    // sorted neighbours: left (Kp, Vp) and right (Kn), across the slots
+    // sorted neighbours: left (Kp, Vp) and right (Kn), across the two slots
     uint32_t ek = K1_KEY_INVALID, ev = 0, en = K1_KEY_INVALID;
     if (j > 0) {
       ek = (uint32_t)__builtin_amdgcn_readlane((int)K[j > 0 ? j - 1 : 0], 63);
@@ -316,140 +238,40 @@ __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, uint3
     const uint32_t Kn = wave_shl1(K[j], en);
     if (K[j] == K1_KEY_INVALID) continue;
     const uint32_t idxl = K[j] >> K1_KEY_IDX_SHIFT;
+    const uint32_t rel = (K[j] >> K1_KEY_REL_SHIFT) & K1_KEY_REL_MASK;
     const bool samep = Kp != K1_KEY_INVALID && (Kp >> K1_KEY_IDX_SHIFT) == idxl;
-    const bool last = Kn == K1_KEY_INVALID || (Kn >> K1_KEY_IDX_SHIFT) != idxl;
-    if (!(K[j] & K1_KEY_TAIL)) { // a run tail already has its chain entry
-      const uint32_t P = samep ? Vp : slice[idxl];
-      const uint32_t pp = P >> cb, pos = V[j] >> cb; // position 0 counts as "empty" (m4.go:152)
-      res[pos - sb] = pp ? ((pos - pp) | ((P & cmask) == (K[j] & cmask) ? kChainMaybe : 0u)) : 0u;
-    }
-    if (last) slice[idxl] = V[j];
-  }
-}
-
-// Staged tile: bytes [A, A + K1_TILE_BYTES) of the source buffer, where A is
-// the 16-byte aligned offset at or below the tile's first position.
-__device__ __forceinline__ int64_t k1_tile_origin(const Job &J, uint32_t base) {
-  return (int64_t)((J.src_off + base) & ~(uint64_t)15);
-}
-
-// Index of a job's tile row in the list buffers.
-__device__ __forceinline__ size_t k1_row(uint32_t slot, uint32_t tmax, uint32_t t, uint32_t nlists) {
-  return ((size_t)slot * tmax + t) * nlists;
-}
-
-__global__ __launch_bounds__(K1_THREADS) void k0_hash_route(
-    const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
-    const Job *__restrict__ jobs, int job0, int njobs, uint32_t *__restrict__ qbuf,
-    uint32_t *__restrict__ qcnt, uint32_t tmax, uint32_t tiles_per_wg, int hash_len, int table_bits,
-    int part_bits, int check_bits, int dbg) {
-  extern __shared__ uint32_t lds[];
-  K1Hash H;
-  H.init(hash_len, table_bits, part_bits, check_bits);
-  const uint32_t nlists = 1u << ((uint32_t)table_bits - H.own_shift);
-  uint32_t *tile = lds;                        // K1_TILE_BYTES/4 dwords
-  uint32_t *lq = tile + K1_TILE_BYTES / 4;     // nlists * K1_QCAP keys
-  uint32_t *cnt = lq + nlists * K1_QCAP;       // 2 * nlists fills (by tile parity)
-
-  const uint32_t nseg = (tmax + tiles_per_wg - 1) / tiles_per_wg;
-  const uint32_t slot = blockIdx.x / nseg, seg = blockIdx.x % nseg;
-  if (slot >= (uint32_t)njobs) return;
-  const Job J = jobs[job0 + slot];
-  uint32_t *chain = chain_base + J.chain_off;
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
-  const uint32_t ntiles = end > J.start ? (end - J.start + K1_SUB - 1) / K1_SUB : 0;
-  const uint32_t t0 = seg * tiles_per_wg, t1 = min(ntiles, t0 + tiles_per_wg);
-  if (t0 >= t1) return;
-
-  for (uint32_t k = tid; k < 2 * nlists; k += K1_THREADS) cnt[k] = 0;
-  uint4 pre = make_uint4(0, 0, 0, 0);
-  if (tid < K1_GROUPS) {
-    pre = load_group(src_base, k1_tile_origin(J, J.start + t0 * K1_SUB) + 16 * (int64_t)tid,
-                     (int64_t)src_total);
-    reinterpret_cast<uint4 *>(tile)[tid] = pre;
-    if (t0 + 1 < t1)
-      pre = load_group(src_base, k1_tile_origin(J, J.start + (t0 + 1) * K1_SUB) + 16 * (int64_t)tid,
-                       (int64_t)src_total);
-  }
-  lds_barrier();
-
-  uint32_t par = 0;
-#pragma unroll 1
-  for (uint32_t t = t0; t < t1; t++, par ^= 1) {
-    const uint32_t sb = J.start + t * K1_SUB;
-    const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
-    uint32_t *mycnt = cnt + par * nlists;
-
-    // phases (loads, hashes, queue atomics, queue writes) so that the LDS
-    // round trips of the K1_PER windows overlap
-    uint2 v[K1_PER];
-    uint32_t key[K1_PER], list[K1_PER], slotq[K1_PER], queued = 0;
-#pragma unroll
-    for (int w = 0; w < K1_PER; w++) v[w] = lds_ld64(tile, lds_off0 + w * K1_THREADS + tid);
-#pragma unroll
-    for (int w = 0; w < K1_PER; w++) {
-      const uint32_t rel = w * K1_THREADS + tid;
-      const uint32_t h = H.hash(v[w]), ck = H.check(v[w]);
-      uint32_t flags;
-      if (k1_fold_window(sb + rel < end, h, ck, sb + rel, chain, !(dbg & 1), flags)) queued |= 1u << w;
-      list[w] = h >> H.own_shift;
-      key[w] = ((h & H.own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | flags | ck;
-    }
-#pragma unroll
-    for (int w = 0; w < K1_PER; w++)
-      if (queued >> w & 1) slotq[w] = atomicAdd(&mycnt[list[w]], 1u);
-#pragma unroll
-    for (int w = 0; w < K1_PER; w++)
-      if ((queued >> w & 1) && slotq[w] < (uint32_t)K1_QCAP) lq[list[w] * K1_QCAP + slotq[w]] = key[w];
-    lds_barrier(); // lists complete
-
-    // flush: fill counts (uncapped: K1 sees an overflow) and the keys, 16
-    // lanes per list so every store instruction writes whole 64-byte rows
-    const size_t row = k1_row(slot, tmax, t, nlists);
-    for (uint32_t l = tid; l < nlists; l += K1_THREADS) qcnt[row + l] = mycnt[l];
-    for (uint32_t l = tid >> 4; l < nlists; l += K1_THREADS / 16) {
-      const uint32_t n = min(mycnt[l], (uint32_t)K1_QCAP);
-      for (uint32_t e = tid & 15; e < n; e += 16) qbuf[(row + l) * K1_QCAP + e] = lq[l * K1_QCAP + e];
-    }
-    // the other parity's counts were flushed one tile ago
-    for (uint32_t l = tid; l < nlists; l += K1_THREADS) cnt[(par ^ 1) * nlists + l] = 0;
-    if (tid < K1_GROUPS && t + 1 < t1) { // stage the next tile, fetch the one after it
-      reinterpret_cast<uint4 *>(tile)[tid] = pre;
-      if (t + 2 < t1)
-        pre = load_group(src_base, k1_tile_origin(J, J.start + (t + 2) * K1_SUB) + 16 * (int64_t)tid,
-                         (int64_t)src_total);
-    }
-    lds_barrier();
+    const bool tail = Kn == K1_KEY_INVALID || (Kn >> K1_KEY_IDX_SHIFT) != idxl;
+    const uint32_t P = samep ? Vp : slice[idxl];
+    const uint32_t pp = P >> cb, pos = sb + rel; // position 0 counts as "empty" (m4.go:152)
+    res[rel] = pp ? ((pos - pp) | ((P & cmask) == (K[j] & cmask) ? kChainMaybe : 0u)) : 0u;
+    if (tail) slice[idxl] = V[j];
   }
 }
 
 __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
-    const Job *__restrict__ jobs, int job0, int njobs, uint32_t *__restrict__ table_io,
-    const uint32_t *__restrict__ qbuf, const uint32_t *__restrict__ qcnt, int qcnt_use, uint32_t tmax, int hash_len, int table_bits, int part_bits,
-    int check_bits, int dbg) {
+    const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
+    int hash_len, int table_bits, int part_bits, int check_bits, int dbg) {
   extern __shared__ uint32_t lds[];
-  K1Hash H;
-  H.init(hash_len, table_bits, part_bits, check_bits);
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
-  uint32_t *res0 = lds + part_size;                 // 2 x K1_SUB chain entries, by tile position
-  uint32_t *qn = res0 + 2 * K1_SUB;                 // K1_WAVES queue fills (redo only)
-  uint32_t *ovf = qn + K1_WAVES;                    // redo overflow flags: slices, K1_PER rows
+  uint32_t *tile = lds + part_size;                 // K1_TILE_BYTES/4 dwords
+  uint32_t *queues = tile + K1_TILE_BYTES / 4;      // K1_WAVES * K1_QCAP keys
+  uint32_t *res = queues + K1_WAVES * K1_QCAP;      // K1_SUB chain entries, by tile position
+  uint8_t *runlen8 = reinterpret_cast<uint8_t *>(res + K1_SUB); // K1_SUB run lengths - 1
+  uint32_t *qn = res + K1_SUB + K1_SUB / 4;         // 2 x K1_WAVES queue fills (by tile parity)
+  uint32_t *ovf = qn + 2 * K1_WAVES;                // overflow flags: 2 by tile parity + K1_PER fallback rows
 
   const int nparts = 1 << (table_bits - part_bits);
-  const uint32_t nown = 1u << ((uint32_t)part_bits - H.own_shift); // owner waves (16 unless tiny table)
-  const uint32_t nlists = (uint32_t)nparts * nown;
   // XCD-aware placement: blocks b and b+8 share an XCD, so give the nparts
   // partitions of one job the same b % 8.
   const uint32_t b = blockIdx.x;
   const uint32_t x = b & 7, r = b >> 3;
   const uint32_t q = r % nparts;
-  const uint32_t slot = (r / nparts) * 8 + x;
-  if (slot >= (uint32_t)njobs) return;
+  const uint32_t job = (r / nparts) * 8 + x;
+  if (job >= (uint32_t)njobs) return;
 
-  const Job J = jobs[job0 + slot];
+  const Job J = jobs[job];
   uint32_t *chain = chain_base + J.chain_off;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -458,160 +280,153 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
 
   for (uint32_t k = tid; k < part_size; k += K1_THREADS)
     table[k] = table_io ? table_io[(q << part_bits) + k] : 0u;
-  for (uint32_t k = tid; k < 2 * K1_SUB; k += K1_THREADS) res0[k] = K1_RES_EMPTY;
-  if (tid < K1_WAVES + 1 + K1_PER) qn[tid] = 0; // fills and overflow flags
-  lds_barrier();
+  if (tid < 2 * K1_WAVES + 2 + K1_PER) qn[tid] = 0; // fills and overflow flags
 
+  // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces:
+  // only the upper dword of the low 64 product bits is needed (table_bits <= 24)
+  const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
+  const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
+  const uint32_t mul_lo = (uint32_t)kHashMul64, mul_hi = (uint32_t)(kHashMul64 >> 32);
+  const uint32_t shift = 32 - table_bits;
+  const uint32_t idx_mask = part_size - 1;
+  const uint32_t own_shift = part_bits > 4 ? part_bits - 4 : 0; // slice = 2^own_shift entries
+  const uint32_t own_mask = (1u << own_shift) - 1;
+  const uint32_t cb = (uint32_t)check_bits; // <= K1_MAX_CHECK_BITS and positions << cb fit 32 bits
   const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
-  const uint32_t ntiles = end > J.start ? (end - J.start + K1_SUB - 1) / K1_SUB : 0;
-  uint32_t *slice = table + (wave << H.own_shift);
-  const bool owner = wave < nown;
-  const uint32_t myl = wave & (nown - 1);
 
-  // Software pipeline over the tiles.  Two tiles ahead every wave fetches the
-  // fill counts of the partition's lists (lanes 0..nown-1) and the first 64
-  // keys of its own list; lists longer than 64 keys fetch the rest when they
-  // are used (rare).  All global accesses of the steady state are
-  // unconditional (clamped addresses, masked stores go to a dump row), so the
-  // waits the compiler inserts are counted ones and never drain the queue.
-  const uint32_t use = qcnt_use ? 1u : 0u; // 0: K0 did not run, the dummy row says "redo" for every tile
-  auto list_row = [&](uint32_t t, uint32_t l) -> size_t {
-    const uint32_t tc = ntiles ? min(t, ntiles - 1) : 0u;
-    return (k1_row(slot, tmax, tc, nlists) + (size_t)q * nown + l) * use;
+  // staged tile: bytes [A, A + K1_TILE_BYTES) of the source buffer, where A is
+  // the 16-byte aligned offset at or below the tile's first position
+  auto tile_origin = [&](uint32_t base) -> int64_t {
+    return (int64_t)((J.src_off + base) & ~(uint64_t)15);
   };
-  // Two register sets (even / odd tiles); a set is refilled for tile t + 2
-  // right after tile t has used it, so no loaded value is ever copied.
-  uint32_t c_ev = qcnt[list_row(0, lane & (nown - 1))];
-  uint32_t k_ev = qbuf[list_row(0, myl) * K1_QCAP + lane];
-  uint32_t c_od = qcnt[list_row(1, lane & (nown - 1))];
-  uint32_t k_od = qbuf[list_row(1, myl) * K1_QCAP + lane];
-  const uint32_t dump = J.dump_rel + (tid & 15); // masked stores land in the job's spare chain slots
+  uint4 pre = make_uint4(0, 0, 0, 0);
+  if (J.start < end && tid < K1_GROUPS) {
+    pre = load_group(src_base, tile_origin(J.start) + 16 * (int64_t)tid, (int64_t)src_total);
+    reinterpret_cast<uint4 *>(tile)[tid] = pre;
+    if (J.start + K1_SUB < end)
+      pre = load_group(src_base, tile_origin(J.start + K1_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
+  }
+  lds_barrier(); // LDS init and the first tile image are in place
 
-  // chain entries of a finished tile back in position order, so that a wave's
-  // stores fall into few cache lines
-  auto store_tile = [&](uint32_t t) {
-    uint32_t *res = res0 + (t & 1) * K1_SUB;
-    const uint32_t sb = J.start + t * K1_SUB;
+  uint32_t par = 0; // tile parity: selects the qn / ovf set
+#pragma unroll 1
+  for (uint32_t sb = J.start; sb < end; sb += K1_SUB, par ^= 1) {
+    const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
+    uint32_t *myqn = qn + par * K1_WAVES;
+
+    // Hash NW windows (64 consecutive positions per wave each, window row
+    // kfirst + w) and queue the run heads of this partition at their owners.
+    // Written in phases (all loads, all hashes, all queue atomics, all queue
+    // writes) so the LDS round trips of the windows overlap.  Returns a bit
+    // per window: this lane queued a key.
+    auto produce = [&](auto nw_tag, int kfirst, bool store_interior, uint32_t *overflow) -> uint32_t {
+      constexpr int NW = decltype(nw_tag)::value;
+      uint2 v[NW];
+      uint32_t key[NW], own[NW], slot[NW], heads = 0;
 #pragma unroll
-    for (int k = 0; k < K1_PER; k++) {
-      const uint32_t rel = k * K1_THREADS + tid;
-      const uint32_t v = res[rel];
-      const bool have = v != K1_RES_EMPTY && !(dbg & 1);
-      res[rel] = K1_RES_EMPTY;
-      chain[have ? sb + rel : dump] = v;
-    }
-  };
-
-  auto tile_step = [&](uint32_t t, uint32_t &c_set, uint32_t &k_set) {
-    const uint32_t sb = J.start + t * K1_SUB;
-    uint32_t *res = res0 + (t & 1) * K1_SUB;
-    // real moves (not coalescable): the set's registers are dead before the
-    // refill is issued, so the loads land in them and the loop carries no
-    // copy of a value that is still in flight
-    uint32_t c_cur, k_cur;
-    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(c_cur), "=&v"(k_cur) : "v"(c_set), "v"(k_set));
-    c_set = qcnt[list_row(t + 2, lane & (nown - 1))];
-    k_set = qbuf[list_row(t + 2, myl) * K1_QCAP + lane];
-    if (t > 0) store_tile(t - 1); // overlaps with this tile's sort
-
-    const bool redo = __ballot(c_cur > (uint32_t)K1_QCAP) != 0; // the same for every wave of the workgroup
-    if (!redo) {
-      const uint32_t n = owner ? (uint32_t)__builtin_amdgcn_readlane((int)c_cur, (int)myl) : 0u;
-      if (n != 0 && !(dbg & 2)) {
-        if (n <= 64) {
-          uint32_t K[1] = {lane < n ? k_cur : K1_KEY_INVALID};
-          k1_consume<1>(slice, res, K, sb, lane, H.cb, SA);
-        } else {
-          const uint32_t *row = qbuf + list_row(t, myl) * K1_QCAP;
-          if (n <= 128) {
-            uint32_t K[2] = {k_cur, 64 + lane < n ? row[64 + lane] : K1_KEY_INVALID};
-            k1_consume<2>(slice, res, K, sb, lane, H.cb, SA);
-          } else {
-            uint32_t K[4] = {k_cur, row[64 + lane], 128 + lane < n ? row[128 + lane] : K1_KEY_INVALID,
-                             192 + lane < n ? row[192 + lane] : K1_KEY_INVALID};
-            k1_consume<4>(slice, res, K, sb, lane, H.cb, SA);
+      for (int w = 0; w < NW; w++) v[w] = lds_ld64(tile, lds_off0 + (kfirst + w) * K1_THREADS + tid);
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        const uint32_t rel = (kfirst + w) * K1_THREADS + tid;
+        const uint32_t lo = v[w].x & mask_lo, hi = v[w].y & mask_hi;
+        const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
+        const bool in = sb + rel < end && (h >> part_bits) == q;
+        // check bits of the first 4 bytes (top bits of a multiplicative hash)
+        const uint32_t ck = cb ? (v[w].x * 0x9E3779B1u) >> (32 - cb) : 0u;
+        // run folding: this position continues the previous one (lane - 1) when
+        // hash and check bits are equal
+        const uint32_t tag = in ? ((h << K1_MAX_CHECK_BITS) | ck) : 0xFFFFFFFFu; // h < 2^24
+        const uint32_t ptag = wave_shr1(tag, 0xFFFFFFFFu);
+        const bool same = in && tag == ptag;
+        const unsigned long long cont = __ballot(same);
+        const uint32_t idx = h & idx_mask;
+        own[w] = idx >> own_shift;
+        key[w] = ((idx & own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | ck;
+        if (in && !same) heads |= 1u << w;
+        if (cont != 0) { // wave-uniform: some run in this window
+          if (same && store_interior && !(dbg & 1))
+            chain[sb + rel] = sb + rel > 1 ? (1u | kChainMaybe) : 0u; // predecessor 0 = "empty"
+          uint32_t runlen1 = 0; // run length - 1
+          if (lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
+          if ((heads >> w & 1) && runlen1) {
+            runlen8[rel] = (uint8_t)runlen1;
+            key[w] |= K1_KEY_RUN;
           }
         }
       }
-    } else {
-      // ---- the workgroup redoes the tile from the source bytes ---------------
-      // Scratch (tile image, owner queues) is laid over the other res[] buffer:
-      // its stores were issued by every thread before it got here.
-      uint32_t *scratch = res0 + ((t & 1) ^ 1) * K1_SUB;
-      uint32_t *tile = scratch;                         // K1_TILE_BYTES/4 dwords
-      uint32_t *queues = scratch + K1_TILE_BYTES / 4;   // K1_WAVES * K1_FQCAP keys
-      const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
-      lds_barrier();
-      if (tid < K1_GROUPS)
-        reinterpret_cast<uint4 *>(tile)[tid] =
-            load_group(src_base, k1_tile_origin(J, sb) + 16 * (int64_t)tid, (int64_t)src_total);
-      if (tid < K1_WAVES + 1 + K1_PER) qn[tid] = 0;
-      lds_barrier();
-      // Hash window row k (64 consecutive positions per wave) and queue this
-      // partition's keys at their owners.
-      auto produce = [&](int k, uint32_t *overflow) {
-        const uint32_t rel = k * K1_THREADS + tid;
-        const uint2 v = lds_ld64(tile, lds_off0 + rel);
-        const uint32_t h = H.hash(v), ck = H.check(v);
-        uint32_t flags;
-        // interior run positions were stored by K0 when it ran; storing them
-        // again writes the same value
-        if (k1_fold_window(sb + rel < end && (h >> part_bits) == q, h, ck, sb + rel, chain, !(dbg & 1),
-                           flags)) {
-          const uint32_t idx = h & H.idx_mask, o = idx >> H.own_shift;
-          const uint32_t key = ((idx & H.own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | flags | ck;
-          const uint32_t s = atomicAdd(&qn[o], 1u);
-          if (s < (uint32_t)K1_FQCAP) queues[o * K1_FQCAP + s] = key;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (heads >> w & 1) slot[w] = atomicAdd(&myqn[own[w]], 1u);
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (heads >> w & 1) {
+          if (slot[w] < (uint32_t)K1_QCAP) queues[own[w] * K1_QCAP + slot[w]] = key[w];
           else *overflow = 1;
         }
-      };
-      auto consume = [&]() {
-        const uint32_t n = owner ? qn[wave] : 0u;
-        if (n == 0) return;
-        const uint32_t *myq = queues + wave * K1_FQCAP;
-        if (n <= 64) {
-          uint32_t K[1] = {lane < n ? myq[lane] : K1_KEY_INVALID};
-          k1_consume<1>(slice, res, K, sb, lane, H.cb, SA);
-        } else {
-          uint32_t K[2] = {myq[lane], 64 + lane < n ? myq[64 + lane] : K1_KEY_INVALID};
-          k1_consume<2>(slice, res, K, sb, lane, H.cb, SA);
-        }
-      };
-#pragma unroll 1
-      for (int k = 0; k < K1_PER; k++) {
-        produce(k, &ovf[1 + k]);
-        lds_barrier();
-        if (!ovf[1 + k]) {
-          consume();
-          lds_barrier();
-          if (tid < K1_WAVES) qn[tid] = 0;
-          lds_barrier();
-          continue;
-        }
-        // the row still overflows some owner: two windows (<= 128 keys) at a time
-        if (tid < K1_WAVES) qn[tid] = 0;
+      return heads;
+    };
+    auto consume = [&]() {
+      const uint32_t n = myqn[wave];
+      if (n == 0) return;
+      uint32_t *slice = table + (wave << own_shift);
+      if (n <= 64) k1_consume<1>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA);
+      else k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA);
+    };
+
+    const uint32_t headmask = produce(std::integral_constant<int, K1_PER>{}, 0, true, &ovf[par]);
+    lds_barrier(); // queues complete
+    if (!(dbg & 2)) {
+      if (!ovf[par]) {
+        consume();
+      } else if (!(dbg & 4)) {
+        // Some owner got more than K1_QCAP keys.  Redo the tile one window row
+        // (1024 positions) at a time; a row that still overflows (short-period
+        // data) is redone in slices of two windows, which hold <= 128 keys in
+        // total and cannot overflow.
+        if (tid < K1_WAVES) myqn[tid] = 0;
         lds_barrier();
 #pragma unroll 1
-        for (uint32_t u = 0; u < (uint32_t)K1_WAVES; u += 2) {
-          if ((wave & ~1u) == u) produce(k, &ovf[0]);
+        for (int k = 0; k < K1_PER; k++) {
+          produce(std::integral_constant<int, 1>{}, k, false, &ovf[2 + k]);
           lds_barrier();
-          consume();
+          if (!ovf[2 + k]) {
+            consume();
+            if (lane == 0) myqn[wave] = 0;
+            lds_barrier();
+            continue;
+          }
+          if (tid < K1_WAVES) myqn[tid] = 0;
           lds_barrier();
-          if (tid < K1_WAVES) qn[tid] = 0;
-          lds_barrier();
+#pragma unroll 1
+          for (uint32_t u = 0; u < (uint32_t)K1_WAVES; u += 2) {
+            if ((wave & ~1u) == u) produce(std::integral_constant<int, 1>{}, k, false, &ovf[2 + k]);
+            lds_barrier();
+            consume();
+            if (lane == 0) myqn[wave] = 0;
+            lds_barrier();
+          }
         }
       }
-      for (uint32_t k = tid; k < K1_SUB; k += K1_THREADS) scratch[k] = K1_RES_EMPTY;
     }
-
-    lds_barrier(); // res[] of this tile complete, res[] of the previous one stored
-  };
-#pragma unroll 1
-  for (uint32_t t = 0; t < ntiles; t += 2) {
-    tile_step(t, c_ev, k_ev);
-    if (t + 1 < ntiles) tile_step(t + 1, c_od, k_od);
+    // stage the next tile (everybody is done reading the current image) and
+    // start fetching the one after it
+    if (tid < K1_GROUPS && sb + K1_SUB < end) {
+      reinterpret_cast<uint4 *>(tile)[tid] = pre;
+      if (sb + 2 * K1_SUB < end)
+        pre = load_group(src_base, tile_origin(sb + 2 * K1_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
+    }
+    lds_barrier(); // res[] complete, next image staged
+    // this parity's counters are next used two tiles from now
+    if (lane == 0) myqn[wave] = 0;
+    if (tid == 0) {
+      if (ovf[par]) ovf[2] = ovf[3] = ovf[4] = 0; // fallback flags, one per window row
+      ovf[par] = 0;
+    }
+    if (dbg & 1) continue; // profiling aid: no chain stores
+#pragma unroll
+    for (int k = 0; k < K1_PER; k++)
+      if (headmask & (1u << k)) chain[sb + k * K1_THREADS + tid] = res[k * K1_THREADS + tid];
   }
-  if (ntiles) store_tile(ntiles - 1);
 
   if (table_io) {
     lds_barrier();
@@ -706,11 +521,7 @@ struct StagedMem {
   }
   // match sources are (almost) never inside the staged range: always global,
   // no branch, so the loads of one iteration issue back to back
-#ifdef M4G_K3_DBG_NOFAR
-  __device__ __forceinline__ uint64_t far64(int32_t p) const { return m4g::ld64(src + (p & 1023)); }
-#else
   __device__ __forceinline__ uint64_t far64(int32_t p) const { return m4g::ld64(src + p); }
-#endif
   __device__ __forceinline__ uint32_t chain_at(int32_t p) const {
     const uint32_t o = (uint32_t)(p - w0);
     if (o < (uint32_t)K3_W) return lch[o];

@@ -86,90 +86,6 @@ int k1_prepare() {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1_chain_build),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)k1_lds_bytes(kMaxPartBits)));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k0_hash_route),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)k0_lds_bytes(K1_MAX_LISTS)));
-  return M4G_OK;
-}
-
-// Key lists between K0 and K1 (kernels.h): per (job of a slice, tile, list) a
-// row of K1_QCAP keys and a fill count.  A batch is processed in slices of
-// `slice_jobs` jobs so the buffer stays a few GiB whatever the batch size.
-struct HashWork {
-  uint32_t *qbuf = nullptr, *qcnt = nullptr;
-  uint32_t tmax = 0;       // tile rows reserved per job
-  uint32_t nlists = 0;     // lists per tile; 0: K0 is not used (more than K1_MAX_LISTS)
-  size_t slice_jobs = 0;
-};
-
-void hash_free(HashWork &h) {
-  (void)hipFree(h.qbuf);
-  (void)hipFree(h.qcnt);
-  h = HashWork{};
-}
-
-constexpr size_t kListBudgetBytes = (size_t)6 << 30;
-
-// Lists for jobs that insert at most max_bytes positions each.
-int hash_alloc(HashWork &h, const Params &p, size_t max_jobs, size_t max_bytes) {
-  hash_free(h);
-  const int pb = part_bits_of(p);
-  const int own_shift = pb > 4 ? pb - 4 : 0;
-  const uint32_t nlists = 1u << (p.table_bits - own_shift);
-  h.tmax = (uint32_t)((max_bytes + K1_SUB - 1) / K1_SUB + 1);
-  h.slice_jobs = std::max<size_t>(1, max_jobs);
-  if (nlists > (uint32_t)K1_MAX_LISTS) {
-    // K1 hashes by itself: one dummy row whose counts say "overflow"
-    if (hipMalloc(&h.qcnt, 64 * 4) != hipSuccess || hipMalloc(&h.qbuf, K1_QCAP * 4) != hipSuccess ||
-        hipMemset(h.qcnt, 0xFF, 64 * 4) != hipSuccess || hipMemset(h.qbuf, 0xFF, K1_QCAP * 4) != hipSuccess) {
-      (void)hipGetLastError();
-      hash_free(h);
-      return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the key lists failed");
-    }
-    return M4G_OK;
-  }
-  const size_t per_job = (size_t)h.tmax * nlists * (K1_QCAP + 1) * 4;
-  h.slice_jobs = std::min(h.slice_jobs, std::max<size_t>(8, kListBudgetBytes / per_job));
-  if (hipMalloc(&h.qbuf, h.slice_jobs * h.tmax * nlists * K1_QCAP * 4) != hipSuccess ||
-      hipMalloc(&h.qcnt, h.slice_jobs * h.tmax * nlists * 4) != hipSuccess) {
-    (void)hipGetLastError();
-    hash_free(h);
-    return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the key lists failed");
-  }
-  h.nlists = nlists;
-  return M4G_OK;
-}
-
-// K0 + K1 over the jobs in d_jobs, slice by slice.
-int launch_chain_build(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
-                       uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs,
-                       const HashWork &h, hipStream_t st, int dbg) {
-  const int pb = part_bits_of(p);
-  const int nparts = 1 << (p.table_bits - pb);
-  // check bits kept next to a position in the LDS table (kernels.h, K1): as
-  // many as fit above the largest position.  The persistent table of a
-  // streaming handle stores plain positions, so no check bits there.
-  int posbits = 1;
-  while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
-  const int cb = d_table_io ? 0 : std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
-  for (int j0 = 0; j0 < njobs; j0 += (int)h.slice_jobs) {
-    const int nj = std::min(njobs - j0, (int)h.slice_jobs);
-    if (h.nlists) {
-      // enough workgroups to fill the chip, each walking consecutive tiles
-      uint32_t nseg = std::min<uint32_t>(h.tmax, std::max<uint32_t>(1, (uint32_t)(4096 / nj)));
-      const uint32_t tiles_per_wg = (h.tmax + nseg - 1) / nseg;
-      nseg = (h.tmax + tiles_per_wg - 1) / tiles_per_wg;
-      hipLaunchKernelGGL(k0_hash_route, dim3((unsigned)nj * nseg), dim3(K1_THREADS),
-                         k0_lds_bytes((int)h.nlists), st, d_src, src_total, d_chain, d_jobs, j0, nj,
-                         h.qbuf, h.qcnt, h.tmax, tiles_per_wg, p.hash_len, p.table_bits, pb, cb, dbg);
-      HIP_TRY(hipGetLastError());
-    }
-    dim3 g1((unsigned)(((nj + 7) / 8) * 8 * nparts));
-    hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, src_total,
-                       d_chain, d_jobs, j0, nj, d_table_io, h.qbuf, h.qcnt, h.nlists ? 1 : 0, h.tmax,
-                       p.hash_len, p.table_bits, pb, cb, dbg);
-    HIP_TRY(hipGetLastError());
-  }
   return M4G_OK;
 }
 
@@ -227,10 +143,21 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes) 
 // On return (stream order) counts[job] holds the job's match count and the
 // records sit in w.rs / w.st as described by w.desc.
 int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
-                uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, const HashWork &h,
-                const SpecWork &w, uint32_t *d_counts, uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
-  int rc0 = launch_chain_build(p, d_src, src_total, max_len, d_chain, d_jobs, d_table_io, njobs, h, st, 0);
-  if (rc0) return rc0;
+                uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, const SpecWork &w, uint32_t *d_counts,
+                uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
+  const int pb = part_bits_of(p);
+  const int nparts = 1 << (p.table_bits - pb);
+  const int groups = (njobs + 7) / 8;
+  dim3 g1((unsigned)(groups * 8 * nparts));
+  // check bits kept next to a position in the LDS table (kernels.h, K1): as
+  // many as fit above the largest position.  The persistent table of a
+  // streaming handle stores plain positions, so no check bits there.
+  int posbits = 1;
+  while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
+  const int cb = d_table_io ? 0 : std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
+  hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, src_total, d_chain,
+                     d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0);
+  HIP_TRY(hipGetLastError());
   if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st));
   const ParseParams P = parse_params(p);
   const uint64_t lanes = (uint64_t)njobs * w.L.kmax;
@@ -312,7 +239,6 @@ struct m4g_batch {
   size_t max_chunks = 0, max_chunk_bytes = 0;
   uint32_t *d_chain = nullptr;
   SpecWork w;
-  HashWork h;
   uint32_t *d_counts = nullptr;
   uint32_t *d_errors = nullptr;
   Job *d_jobs = nullptr;
@@ -327,7 +253,6 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipSetDevice(b->device);
   (void)hipFree(b->d_chain);
   spec_free(b->w);
-  hash_free(b->h);
   (void)hipFree(b->d_counts);
   (void)hipFree(b->d_errors);
   (void)hipFree(b->d_jobs);
@@ -357,13 +282,12 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   b->max_chunks = max_chunks;
   b->max_chunk_bytes = max_chunk_bytes;
   const size_t nbytes = max_chunks * max_chunk_bytes;
-  if ((rc = spec_alloc(b->w, p, max_chunks, max_chunk_bytes)) ||
-      (rc = hash_alloc(b->h, p, max_chunks, max_chunk_bytes))) {
+  if ((rc = spec_alloc(b->w, p, max_chunks, max_chunk_bytes))) {
     m4g_batch_destroy(b);
     return rc;
   }
   hipError_t e;
-  if ((e = hipMalloc(&b->d_chain, (nbytes + 32 * max_chunks) * 4 + 4096)) != hipSuccess ||
+  if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 4096)) != hipSuccess ||
       (e = hipMalloc(&b->d_counts, max_chunks * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_errors, 64)) != hipSuccess ||
       (e = hipMalloc(&b->d_jobs, max_chunks * sizeof(Job))) != hipSuccess) {
@@ -419,8 +343,8 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
       J.start = 0;
       J.len = (uint32_t)n;
       J.seed_prev = 0;
-      J.dump_rel = (uint32_t)((n + 15) & ~(uint64_t)15);
-      chain_off += ((n + 15) & ~(uint64_t)15) + 16;
+      J.pad = 0;
+      chain_off += (n + 15) & ~(uint64_t)15;
     }
     // pageable source: the runtime stages it before returning, so `jobs` may die.
     HIP_TRY(hipMemcpyAsync(b->d_jobs, jobs.data(), nchunks * sizeof(Job), hipMemcpyHostToDevice, st));
@@ -429,7 +353,7 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
 
   HIP_TRY(hipMemsetAsync(b->d_errors, 0, 4, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  int rc = launch_find(b->p, d_src, chunk_off[nchunks], (uint32_t)b->max_chunk_bytes, b->d_chain, b->d_jobs, nullptr, njobs, b->h, b->w, b->d_counts,
+  int rc = launch_find(b->p, d_src, chunk_off[nchunks], (uint32_t)b->max_chunk_bytes, b->d_chain, b->d_jobs, nullptr, njobs, b->w, b->d_counts,
                        b->d_errors, st, b->timing ? b->ev[1] : nullptr);
   if (rc) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -453,17 +377,19 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
 
 // Profiling aid (not part of include/m4g.h): runs K1 alone `reps` times on the
 // job list of the last m4g_batch_run_device call and returns the average ms.
-// dbg bit 0: skip the chain stores; bit 1: K0 and the list loads only.
+// dbg bit 0: skip the chain stores; bit 1: hashing + compaction only.
 extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t src_total, int njobs,
                                  int dbg, int reps, float *ms_out) {
   if (!b || !ms_out || njobs <= 0 || (size_t)njobs > b->max_chunks) return fail(M4G_ERR_BAD_PARAM, "bad argument");
   HIP_TRY(hipSetDevice(b->device));
+  const int pb = part_bits_of(b->p);
+  const int nparts = 1 << (b->p.table_bits - pb);
+  dim3 g1((unsigned)(((njobs + 7) / 8) * 8 * nparts));
   HIP_TRY(hipEventRecord(b->ev[0], nullptr));
-  for (int r = 0; r < reps; r++) {
-    int rc = launch_chain_build(b->p, d_src, src_total, (uint32_t)b->max_chunk_bytes, b->d_chain, b->d_jobs,
-                                nullptr, njobs, b->h, nullptr, dbg);
-    if (rc) return rc;
-  }
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), nullptr, d_src, src_total,
+                       b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[1], nullptr));
   HIP_TRY(hipEventSynchronize(b->ev[1]));
   HIP_TRY(hipEventElapsedTime(ms_out, b->ev[0], b->ev[1]));
@@ -677,7 +603,6 @@ struct m4g_ctx {
   int64_t hist_len = 0;
   uint32_t *d_table = nullptr;
   SpecWork w;
-  HashWork h;
   size_t w_bytes = 0;           // block size the parse workspace was sized for
   m4g_match *d_out = nullptr;   // compacted matches of the last block
   uint64_t *d_out_off = nullptr;
@@ -697,7 +622,6 @@ extern "C" void m4g_destroy(m4g_ctx *c) {
   (void)hipFree(c->d_chain);
   (void)hipFree(c->d_table);
   spec_free(c->w);
-  hash_free(c->h);
   (void)hipFree(c->d_out);
   (void)hipFree(c->d_out_off);
   (void)hipFree(c->d_counts);
@@ -807,7 +731,7 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   if (rc) return rc;
   if (c->w_bytes < n) {
     size_t nb = std::max(n, (size_t)1 << 16);
-    if ((rc = spec_alloc(c->w, p, 1, nb)) || (rc = hash_alloc(c->h, p, 1, nb))) return rc;
+    if ((rc = spec_alloc(c->w, p, 1, nb))) return rc;
     c->w_bytes = nb;
   }
   if (c->out_cap < need) {
@@ -830,13 +754,12 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   J.start = (uint32_t)c->hist_len;
   J.len = (uint32_t)(c->hist_len + (int64_t)n);
   J.seed_prev = seed_prev_distance;
-  J.dump_rel = (uint32_t)c->cap; // the 4096 spare bytes behind the chain buffer
   HIP_TRY(hipMemcpyAsync(c->d_job, &J, sizeof(Job), hipMemcpyHostToDevice, c->st));
   HIP_TRY(hipMemsetAsync(c->d_counts, 0, 8, c->st));
   // positions in [start, len-7) that K1 does not visit keep chain = 0 only if
   // cleared: the last 7 of every block are never inserted (m4.go:112).
   HIP_TRY(hipMemsetAsync(c->d_chain + c->hist_len, 0, n * 4, c->st));
-  rc = launch_find(p, c->d_hist, (uint64_t)c->hist_len + n, (uint32_t)(c->hist_len + (int64_t)n), c->d_chain, c->d_job, c->d_table, 1, c->h, c->w, c->d_counts,
+  rc = launch_find(p, c->d_hist, (uint64_t)c->hist_len + n, (uint32_t)(c->hist_len + (int64_t)n), c->d_chain, c->d_job, c->d_table, 1, c->w, c->d_counts,
                    c->d_counts + 1, c->st, nullptr);
   if (rc) return rc;
   if ((rc = launch_compact(c->w, c->d_job, c->d_counts, 1, c->d_out_off, c->d_out, c->out_cap, c->st)))
