@@ -65,6 +65,23 @@ def cpu_baseline(host: np.ndarray, chunk_bytes: int, kw: dict, nchunks: int, thr
     return nchunks * chunk_bytes / dt / 1e9
 
 
+def pmc_traffic(kernel: str, args, input_bytes: int):
+    """HBM-side bytes per launch of `kernel` (GB), from the rocprofv3 --pmc passes
+    committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be collected
+    inside this process; tools/pmc_traffic.py turns the two passes into
+    bytes per input byte for one workload, scaled here to this launch).
+    None when no measurement for this workload is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    key = f"{args.kind}/{args.params}"
+    per_byte = t.get(key, {}).get(kernel)
+    return None if per_byte is None else round(per_byte * input_bytes / 1e9, 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,9 +170,10 @@ def main():
         raise SystemExit(f"output capacity too small: {total_matches} > {out_cap}")
 
     # ---- parity gate on a sample (untimed) ---------------------------------
-    from oracle_lib import OracleM4, histograms
+    from oracle_lib import OracleEncoder, OracleM4, brotli_decompress, histograms
     o = d_off.cpu().numpy()
     verified = 0
+    stream_bytes = roundtrips = 0
     for c in np.linspace(0, C - 1, num=min(args.verify_chunks, C), dtype=int):
         chunk = host[c * n:(c + 1) * n]
         ref = OracleM4(**kw).FindMatches(chunk)
@@ -167,6 +185,16 @@ def main():
             h = d_h[c * 1024:(c + 1) * 1024].cpu().numpy().view(np.uint32)
             if not ((h[:256] == lit).all() and (h[256:960] == cmd).all() and (h[960:] == dst).all()):
                 raise SystemExit(f"HISTOGRAM PARITY FAILURE on chunk {c}")
+        # the reference's own criterion (brotli_test.go:626-649): the stream the
+        # restated Encoder builds from the GPU's matches decodes back to the input
+        stream = OracleEncoder().Encode(chunk, got, True)
+        stream_bytes += len(stream)
+        try:
+            if brotli_decompress(stream, n) != chunk.tobytes():
+                raise SystemExit(f"ROUND TRIP FAILURE on chunk {c}")
+            roundtrips += 1
+        except RuntimeError:
+            pass  # no libbrotlidec on this box: ratio only
         verified += 1
 
     if rank != 0:
@@ -205,6 +233,8 @@ def main():
             "histograms": d_h is not None,
             "matches_per_MiB": round(total_matches / (C * n / 2**20), 1),
             "parity_checked_chunks": verified,
+            "roundtrip_checked_chunks": roundtrips,
+            "compression_ratio": round(verified * n / stream_bytes, 3) if stream_bytes else None,
         },
         "stage_ms": {names[k]: round(float(stage_ms[k]), 3) for k in range(4)},
         "roofline": {
@@ -214,7 +244,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": pmc_traffic(names[dom], args, n * C),
             "algorithmic_bytes_per_launch": alg_bytes,
         },
     }
