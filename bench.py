@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=384)
     ap.add_argument("--verify-chunks", type=int, default=8)
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--e2e-sample-chunks", type=int, default=512)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,6 +262,23 @@ def main():
             "sample": f"first {sample} chunks of the same workload ({sample * n / 2**20:.0f} MiB), "
                       f"C restatement of the reference's M4 (oracle/m4_ref.c; Go is unavailable), "
                       f"{threads} threads, one M4 per thread, Reset per chunk",
+        }
+    if not args.no_end_to_end and world == 1:
+        # PCIe-inclusive rate of the host-memory API on a bounded sample: wall
+        # clock from the first H2D enqueue to the last D2H completion (SURVEY
+        # 8d "end-to-end").  Reported beside `value`, never as `value`.
+        sample = min(C, args.e2e_sample_chunks)
+        del plan, d_out, d_off, d_h, d_src
+        torch.cuda.empty_cache()
+        sub_off = off[:sample + 1]
+        m4.find_matches_batch(host[:n * min(sample, 8)], off[:min(sample, 8) + 1], (local_rank,), True, **kw)  # warm
+        t0 = time.perf_counter()
+        m4.find_matches_batch(host[:n * sample], sub_off, (local_rank,), True, **kw)
+        dt = time.perf_counter() - t0
+        out["end_to_end"] = {
+            "value": round(sample * n / dt / 1e9, 3), "unit": "GB/s",
+            "sample": f"m4g_find_matches_batch on the first {sample} chunks from pageable host memory: "
+                      f"workspace allocation + H2D + kernels + D2H of matches and histograms",
         }
     print(json.dumps(out), flush=True)
     if dist is not None:

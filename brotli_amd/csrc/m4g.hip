@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -437,6 +438,19 @@ void free_part(DevPart &P) {
 }
 } // namespace
 
+namespace {
+struct Trace {
+  bool on = std::getenv("M4G_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char *what) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[m4g] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+} // namespace
+
 extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
                                           const uint64_t *chunk_off, size_t nchunks,
                                           const int *devices, int ndevices, m4g_match *out,
@@ -457,12 +471,14 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
   for (int g = 0; g < ndevices; g++)
     if ((rc = check_device(devices[g]))) return rc;
 
+  Trace tr;
   // pin the caller's buffers for the duration when possible (faster copies)
   const size_t total = chunk_off[nchunks] - chunk_off[0];
-  bool pinned_in = total && hipHostRegister(const_cast<uint8_t *>(base) + chunk_off[0], total,
+  bool pinned_in = total && !std::getenv("M4G_NO_PIN") && hipHostRegister(const_cast<uint8_t *>(base) + chunk_off[0], total,
                                             hipHostRegisterDefault) == hipSuccess;
   (void)hipGetLastError();
 
+  tr.mark("pin input");
   std::vector<DevPart> parts(ndevices);
   int64_t result = M4G_OK;
   auto cleanup = [&]() {
@@ -498,16 +514,23 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
       cleanup();
       return rc;
     }
+    tr.mark("plan create");
     BATCH_TRY(hipMalloc(&P.d_src, P.off.back() + 64));
     BATCH_TRY(hipMalloc(&P.d_out, P.out_cap * sizeof(m4g_match)));
     BATCH_TRY(hipMalloc(&P.d_out_off, (P.chunks.size() + 1) * 8));
     if (histos) BATCH_TRY(hipMalloc(&P.d_histos, P.chunks.size() * sizeof(m4g_histo)));
-    for (size_t k = 0; k < P.chunks.size(); k++) {
-      size_t c = P.chunks[k];
-      uint64_t n = chunk_off[c + 1] - chunk_off[c];
-      if (n)
-        BATCH_TRY(hipMemcpyAsync(P.d_src + P.off[k], base + chunk_off[c], n, hipMemcpyHostToDevice, P.st));
+    if (ndevices == 1) { // the device's chunks are the caller's buffer: one copy
+      if (total)
+        BATCH_TRY(hipMemcpyAsync(P.d_src, base + chunk_off[0], total, hipMemcpyHostToDevice, P.st));
+    } else {
+      for (size_t k = 0; k < P.chunks.size(); k++) {
+        size_t c = P.chunks[k];
+        uint64_t n = chunk_off[c + 1] - chunk_off[c];
+        if (n)
+          BATCH_TRY(hipMemcpyAsync(P.d_src + P.off[k], base + chunk_off[c], n, hipMemcpyHostToDevice, P.st));
+      }
     }
+    tr.mark("alloc + H2D enqueue");
     P.h_out_off.resize(P.chunks.size() + 1);
     rc = m4g_batch_run_device(P.plan, P.d_src, P.off.data(), P.chunks.size(), P.d_out, P.d_out_off,
                               P.out_cap, P.d_histos, P.st);
@@ -519,6 +542,7 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
                              hipMemcpyDeviceToHost, P.st));
   }
 
+  tr.mark("launch");
   // 2. global offsets in chunk order
   for (int g = 0; g < ndevices; g++) {
     DevPart &P = parts[g];
@@ -533,6 +557,7 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
                       : fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
     }
   }
+  tr.mark("kernels done");
   uint64_t run = 0;
   for (size_t c = 0; c < nchunks; c++) {
     DevPart &P = parts[c % (size_t)ndevices];
@@ -547,12 +572,18 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
   }
 
   // 3. ordered concatenation on the host: each chunk's list lands at out_off[c]
-  bool pinned_out = run && hipHostRegister(out, run * sizeof(m4g_match), hipHostRegisterDefault) == hipSuccess;
+  bool pinned_out = run && !std::getenv("M4G_NO_PIN") &&
+                    hipHostRegister(out, run * sizeof(m4g_match), hipHostRegisterDefault) == hipSuccess;
+  tr.mark("pin output");
   (void)hipGetLastError();
   for (size_t c = 0; c < nchunks; c++) {
     DevPart &P = parts[c % (size_t)ndevices];
     size_t k = c / (size_t)ndevices;
     uint64_t cnt = P.h_out_off[k + 1] - P.h_out_off[k];
+    if (ndevices == 1) { // already in chunk order on the device: one copy
+      if (c != 0) break;
+      cnt = run;
+    }
     if (!cnt) continue;
     hipError_t e = hipSetDevice(P.device);
     if (e == hipSuccess)
@@ -584,8 +615,10 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
       (void)hipSetDevice(P.device);
       (void)hipStreamSynchronize(P.st);
     }
+  tr.mark("D2H");
   if (pinned_out) (void)hipHostUnregister(out);
   cleanup();
+  tr.mark("cleanup");
   return result;
 #undef BATCH_TRY
 }

@@ -319,4 +319,4 @@ def find_matches_batch(base, chunk_off: Sequence[int], devices: Sequence[int] = 
     if r < 0:
         raise M4GError(f"m4g_find_matches_batch: out_cap too small, need {-r}")
     total = int(out_off[n])
-    return out[:total].copy(), out_off, (histos[:n] if want_histos else None)
+    return out[:total], out_off, (histos[:n] if want_histos else None)
