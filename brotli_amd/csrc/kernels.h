@@ -27,7 +27,32 @@ struct Job {
   uint32_t start;     // first position to insert / parse (e.NextEmit at entry)
   uint32_t len;       // buffer length (positions [start, len-7) are inserted)
   uint32_t seed_prev; // Distance of the caller's last dst element, 0 = none
+  uint32_t store_from; // K1 only: positions in [start, store_from) are inserted but get no chain entry
+                       // (table priming of a stream segment); 0 otherwise
+  uint32_t k1_flags;   // K1 only, with a persistent table: kJobLoadTable | kJobStoreTable
   uint32_t pad;
+};
+constexpr uint32_t kJobLoadTable = 1, kJobStoreTable = 2;
+
+// Block structure of one stream handled in a single launch ("window primed",
+// SURVEY.md section 8f.1): what a sequence of FindMatches calls on consecutive
+// blocks does to the hash table, restated for workgroups that each build the
+// chain of one segment of the stream.
+//   * the last 7 positions of every block are never inserted (m4.go:112);
+//   * a history slide (m4.go:82-99) turns every table entry at or below the new
+//     buffer origin into "empty"; origins only grow, so it is enough to test a
+//     predecessor against the origin in force at the position that reads it.
+// Positions are buffer positions at the time of the call (after its first
+// slide, if any).
+constexpr int kStreamMaxSlides = 4096;
+struct StreamInfo {
+  uint32_t x0;          // first position of the call's data (= start of block 0)
+  uint32_t x_end;       // end of the call's data
+  uint32_t block_size;  // >= K1_SUB + 7: at most one block end per tile
+  uint32_t nbp;         // slide breakpoints in use (>= 1; entry 0 = {0, 0})
+  uint32_t final_org;   // origin after the call: table entries are stored relative to it
+  uint32_t bp_x[kStreamMaxSlides];   // first position (block start) governed by bp_org[k]
+  uint32_t bp_org[kStreamMaxSlides]; // buffer origin from there on (ascending)
 };
 
 constexpr uint64_t kHashMul64 = 0x1E35A7BD1E35A7BDull; // m4.go:285
@@ -202,7 +227,8 @@ __device__ __forceinline__ uint32_t k1_sort64(uint32_t K, uint32_t lane, const K
 template <int NJ>
 __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const uint8_t *runlen8,
                                            const uint32_t *myq, uint32_t n, uint32_t sb,
-                                           uint32_t lane, uint32_t cb, const K1SortAddr &A) {
+                                           uint32_t lane, uint32_t cb, const K1SortAddr &A,
+                                           uint32_t org_cur, uint32_t org_next_x, uint32_t org_next) {
   const uint32_t cmask = (1u << cb) - 1;
   uint32_t K[NJ], V[NJ];
 #pragma unroll
@@ -242,8 +268,9 @@ __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const
     const bool samep = Kp != K1_KEY_INVALID && (Kp >> K1_KEY_IDX_SHIFT) == idxl;
     const bool tail = Kn == K1_KEY_INVALID || (Kn >> K1_KEY_IDX_SHIFT) != idxl;
     const uint32_t P = samep ? Vp : slice[idxl];
-    const uint32_t pp = P >> cb, pos = sb + rel; // position 0 counts as "empty" (m4.go:152)
-    res[rel] = pp ? ((pos - pp) | ((P & cmask) == (K[j] & cmask) ? kChainMaybe : 0u)) : 0u;
+    // a predecessor at or below the buffer origin counts as "empty" (m4.go:152, 92-98)
+    const uint32_t pp = P >> cb, pos = sb + rel, org = pos >= org_next_x ? org_next : org_cur;
+    res[rel] = pp > org ? ((pos - pp) | ((P & cmask) == (K[j] & cmask) ? kChainMaybe : 0u)) : 0u;
     if (tail) slice[idxl] = V[j];
   }
 }
@@ -251,7 +278,8 @@ __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const
 __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
-    int hash_len, int table_bits, int part_bits, int check_bits, int dbg) {
+    int hash_len, int table_bits, int part_bits, int check_bits, int dbg,
+    const StreamInfo *__restrict__ si, uint32_t *__restrict__ table_out) {
   extern __shared__ uint32_t lds[];
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
@@ -278,9 +306,16 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   const K1SortAddr SA = {(int)((lane ^ 16) << 2), (int)((lane ^ 32) << 2), (int)((lane ^ 31) << 2),
                          (int)((lane ^ 63) << 2)};
 
+  const bool load_table = table_io && (J.k1_flags & kJobLoadTable);
+  const bool store_table = table_io && (J.k1_flags & kJobStoreTable);
   for (uint32_t k = tid; k < part_size; k += K1_THREADS)
-    table[k] = table_io ? table_io[(q << part_bits) + k] : 0u;
+    table[k] = load_table ? table_io[(q << part_bits) + k] : 0u;
   if (tid < 2 * K1_WAVES + 2 + K1_PER) qn[tid] = 0; // fills and overflow flags
+  // block structure of a stream handled in one launch (none: one block, origin 0)
+  const uint32_t st_x0 = si ? si->x0 : 0u, st_xend = si ? si->x_end : 0xFFFFFFFFu;
+  const uint32_t st_block = si ? si->block_size : 0u, st_nbp = si ? si->nbp : 1u;
+  uint32_t bpi = 0; // breakpoint in force at the current tile
+  const uint32_t store_from = J.store_from;
 
   // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces:
   // only the upper dword of the low 64 product bits is needed (table_bits <= 24)
@@ -313,6 +348,21 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   for (uint32_t sb = J.start; sb < end; sb += K1_SUB, par ^= 1) {
     const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
     uint32_t *myqn = qn + par * K1_WAVES;
+    // origin in force at the tile start, and the next change (at most one per
+    // tile: slides are more than MaxDistance >= K1_SUB positions apart)
+    uint32_t org_cur = 0, org_next_x = 0xFFFFFFFFu, org_next = 0;
+    // end of the block the tile starts in: its last 7 positions are not inserted
+    uint32_t blk_end = 0xFFFFFFFFu;
+    if (si) {
+      while (bpi + 1 < st_nbp && si->bp_x[bpi + 1] <= sb) bpi++;
+      org_cur = si->bp_org[bpi];
+      if (bpi + 1 < st_nbp) {
+        org_next_x = si->bp_x[bpi + 1];
+        org_next = si->bp_org[bpi + 1];
+      }
+      if (sb >= st_x0) blk_end = min(st_xend, st_x0 + ((sb - st_x0) / st_block + 1) * st_block);
+      else blk_end = st_x0; // history of earlier calls is never re-inserted (segments start at x0)
+    }
 
     // Hash NW windows (64 consecutive positions per wave each, window row
     // kfirst + w) and queue the run heads of this partition at their owners.
@@ -330,7 +380,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
         const uint32_t rel = (kfirst + w) * K1_THREADS + tid;
         const uint32_t lo = v[w].x & mask_lo, hi = v[w].y & mask_hi;
         const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
-        const bool in = sb + rel < end && (h >> part_bits) == q;
+        const uint32_t pos = sb + rel;
+        const bool in = pos < end && (h >> part_bits) == q && !(pos + 7 >= blk_end && pos < blk_end);
         // check bits of the first 4 bytes (top bits of a multiplicative hash)
         const uint32_t ck = cb ? (v[w].x * 0x9E3779B1u) >> (32 - cb) : 0u;
         // run folding: this position continues the previous one (lane - 1) when
@@ -344,8 +395,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
         key[w] = ((idx & own_mask) << K1_KEY_IDX_SHIFT) | (rel << K1_KEY_REL_SHIFT) | ck;
         if (in && !same) heads |= 1u << w;
         if (cont != 0) { // wave-uniform: some run in this window
-          if (same && store_interior && !(dbg & 1))
-            chain[sb + rel] = sb + rel > 1 ? (1u | kChainMaybe) : 0u; // predecessor 0 = "empty"
+          if (same && store_interior && !(dbg & 1) && pos >= store_from) // predecessor at the origin = "empty"
+            chain[pos] = pos - 1 > (pos >= org_next_x ? org_next : org_cur) ? (1u | kChainMaybe) : 0u;
           uint32_t runlen1 = 0; // run length - 1
           if (lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
           if ((heads >> w & 1) && runlen1) {
@@ -369,8 +420,10 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
       const uint32_t n = myqn[wave];
       if (n == 0) return;
       uint32_t *slice = table + (wave << own_shift);
-      if (n <= 64) k1_consume<1>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA);
-      else k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA);
+      if (n <= 64)
+        k1_consume<1>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA, org_cur, org_next_x, org_next);
+      else
+        k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA, org_cur, org_next_x, org_next);
     };
 
     const uint32_t headmask = produce(std::integral_constant<int, K1_PER>{}, 0, true, &ovf[par]);
@@ -425,13 +478,17 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     if (dbg & 1) continue; // profiling aid: no chain stores
 #pragma unroll
     for (int k = 0; k < K1_PER; k++)
-      if (headmask & (1u << k)) chain[sb + k * K1_THREADS + tid] = res[k * K1_THREADS + tid];
+      if ((headmask & (1u << k)) && sb + k * K1_THREADS + tid >= store_from)
+        chain[sb + k * K1_THREADS + tid] = res[k * K1_THREADS + tid];
   }
 
-  if (table_io) {
+  if (store_table) { // entries relative to the origin after the call, at or below it = empty
+    const uint32_t rebase = si ? si->final_org : 0u;
     lds_barrier();
-    for (uint32_t k = tid; k < part_size; k += K1_THREADS)
-      table_io[(q << part_bits) + k] = table[k];
+    for (uint32_t k = tid; k < part_size; k += K1_THREADS) {
+      const uint32_t v = table[k];
+      (table_out ? table_out : table_io)[(q << part_bits) + k] = v > rebase ? v - rebase : 0u;
+    }
   }
 }
 

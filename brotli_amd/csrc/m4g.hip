@@ -143,9 +143,11 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes) 
 // Launches K1 + K3 for `njobs` jobs whose descriptors are already in d_jobs.
 // On return (stream order) counts[job] holds the job's match count and the
 // records sit in w.rs / w.st as described by w.desc.
-int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
-                uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, const SpecWork &w, uint32_t *d_counts,
-                uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
+// K1 for the jobs in d_jobs.  d_si: block structure when the jobs are segments
+// of one stream (null otherwise).
+int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
+              uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, hipStream_t st,
+              const StreamInfo *d_si, uint32_t *d_table_out = nullptr) {
   const int pb = part_bits_of(p);
   const int nparts = 1 << (p.table_bits - pb);
   const int groups = (njobs + 7) / 8;
@@ -157,9 +159,17 @@ int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint3
   while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
   const int cb = d_table_io ? 0 : std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
   hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, src_total, d_chain,
-                     d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0);
+                     d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out);
   HIP_TRY(hipGetLastError());
-  if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st));
+  return M4G_OK;
+}
+
+// K3 for the jobs in d_jobs, whose chain entries K1 has produced.  On return
+// (stream order) counts[job] holds the job's match count and the records sit
+// in w.rs / w.st as described by w.desc.
+int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, const uint32_t *d_chain,
+                 const Job *d_jobs, int njobs, const SpecWork &w, uint32_t *d_counts, uint32_t *d_errors,
+                 hipStream_t st) {
   const ParseParams P = parse_params(p);
   const uint64_t lanes = (uint64_t)njobs * w.L.kmax;
   const unsigned g3 = (unsigned)((lanes + K3_THREADS - 1) / K3_THREADS);
@@ -177,6 +187,16 @@ int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint3
   return M4G_OK;
 }
 
+// K1 + K3 for `njobs` jobs whose descriptors are already in d_jobs.
+int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
+                uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, const SpecWork &w, uint32_t *d_counts,
+                uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
+  int rc = launch_k1(p, d_src, src_total, max_len, d_chain, d_jobs, d_table_io, njobs, st, nullptr);
+  if (rc) return rc;
+  if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st));
+  return launch_parse(p, d_src, src_total, d_chain, d_jobs, njobs, w, d_counts, d_errors, st);
+}
+
 // K4 for jobs already through launch_find: offsets, then the records.
 int launch_compact(const SpecWork &w, const Job *d_jobs, const uint32_t *d_counts, int njobs,
                    uint64_t *d_out_off, m4g_match *d_out, size_t out_cap, hipStream_t st) {
@@ -190,6 +210,19 @@ int launch_compact(const SpecWork &w, const Job *d_jobs, const uint32_t *d_count
   return M4G_OK;
 }
 
+} // namespace
+
+namespace {
+struct Trace {
+  bool on = std::getenv("M4G_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char *what) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[m4g] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 } // namespace
 
 // ===========================================================================
@@ -344,6 +377,8 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
       J.start = 0;
       J.len = (uint32_t)n;
       J.seed_prev = 0;
+      J.store_from = 0;
+      J.k1_flags = 0;
       J.pad = 0;
       chain_off += (n + 15) & ~(uint64_t)15;
     }
@@ -389,7 +424,7 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
   HIP_TRY(hipEventRecord(b->ev[0], nullptr));
   for (int r = 0; r < reps; r++)
     hipLaunchKernelGGL(k1_chain_build, g1, dim3(K1_THREADS), k1_lds_bytes(pb), nullptr, d_src, src_total,
-                       b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg);
+                       b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[1], nullptr));
   HIP_TRY(hipEventSynchronize(b->ev[1]));
@@ -438,18 +473,6 @@ void free_part(DevPart &P) {
 }
 } // namespace
 
-namespace {
-struct Trace {
-  bool on = std::getenv("M4G_TRACE") != nullptr;
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  void mark(const char *what) {
-    if (!on) return;
-    auto t1 = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[m4g] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-    t0 = t1;
-  }
-};
-} // namespace
 
 extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
                                           const uint64_t *chunk_off, size_t nchunks,
@@ -643,6 +666,17 @@ struct m4g_ctx {
   uint32_t *d_counts = nullptr; // [0] count, [1] errors
   Job *d_job = nullptr;
   m4g_match *h_recs = nullptr; // pinned staging
+  // block-parallel mode (m4g_find_matches_blocks)
+  SpecWork wb;                  // parse workspace for wb_jobs blocks of wb_bytes
+  size_t wb_jobs = 0, wb_bytes = 0;
+  Job *d_bjobs = nullptr;       // segment jobs (K1) followed by block jobs (K3..)
+  size_t bjobs_cap = 0;
+  StreamInfo *d_si = nullptr;
+  uint32_t *d_table2 = nullptr; // the segments of one call read d_table and write this one; then swapped
+  uint32_t *d_bcounts = nullptr;
+  uint64_t *d_boff = nullptr;
+  uint8_t *d_tmp = nullptr;     // scratch for the history move after a call
+  size_t tmp_cap = 0;
   uint64_t *h_off = nullptr;   // pinned, 2 words
   uint32_t *h_counts = nullptr; // pinned, 2 words
 };
@@ -655,6 +689,13 @@ extern "C" void m4g_destroy(m4g_ctx *c) {
   (void)hipFree(c->d_chain);
   (void)hipFree(c->d_table);
   spec_free(c->w);
+  spec_free(c->wb);
+  (void)hipFree(c->d_bjobs);
+  (void)hipFree(c->d_si);
+  (void)hipFree(c->d_table2);
+  (void)hipFree(c->d_bcounts);
+  (void)hipFree(c->d_boff);
+  (void)hipFree(c->d_tmp);
   (void)hipFree(c->d_out);
   (void)hipFree(c->d_out_off);
   (void)hipFree(c->d_counts);
@@ -730,6 +771,27 @@ int ctx_reserve(m4g_ctx *c, size_t need) {
 }
 } // namespace
 
+namespace {
+// m4.go:82-99: slide.  delta > MaxDistance here, so source and destination of
+// the copies do not overlap.
+int ctx_slide(m4g_ctx *c) {
+  const Params &p = c->p;
+  if (c->hist_len > 2 * (int64_t)p.max_distance) {
+    const int64_t delta = c->hist_len - p.max_distance;
+    HIP_TRY(hipMemcpyAsync(c->d_hist, c->d_hist + delta, (size_t)p.max_distance,
+                           hipMemcpyDeviceToDevice, c->st));
+    HIP_TRY(hipMemcpyAsync(c->d_chain, c->d_chain + delta, (size_t)p.max_distance * 4,
+                           hipMemcpyDeviceToDevice, c->st));
+    const uint32_t tn = 1u << p.table_bits;
+    hipLaunchKernelGGL(ks_rebase_table, dim3((tn + 255) / 256), dim3(256), 0, c->st, c->d_table, tn,
+                       (uint32_t)delta);
+    HIP_TRY(hipGetLastError());
+    c->hist_len = p.max_distance;
+  }
+  return M4G_OK;
+}
+} // namespace
+
 extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
                                     uint32_t seed_prev_distance, m4g_match *out, size_t out_cap) {
   if (!c || (!src && n) || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
@@ -744,20 +806,7 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   }
   HIP_TRY(hipSetDevice(c->device));
 
-  // m4.go:82-99: slide.  delta > MaxDistance here, so source and destination of
-  // the copies do not overlap.
-  if (c->hist_len > 2 * (int64_t)p.max_distance) {
-    const int64_t delta = c->hist_len - p.max_distance;
-    HIP_TRY(hipMemcpyAsync(c->d_hist, c->d_hist + delta, (size_t)p.max_distance,
-                           hipMemcpyDeviceToDevice, c->st));
-    HIP_TRY(hipMemcpyAsync(c->d_chain, c->d_chain + delta, (size_t)p.max_distance * 4,
-                           hipMemcpyDeviceToDevice, c->st));
-    const uint32_t tn = 1u << p.table_bits;
-    hipLaunchKernelGGL(ks_rebase_table, dim3((tn + 255) / 256), dim3(256), 0, c->st, c->d_table, tn,
-                       (uint32_t)delta);
-    HIP_TRY(hipGetLastError());
-    c->hist_len = p.max_distance;
-  }
+  { int rc0 = ctx_slide(c); if (rc0) return rc0; }
   if (n == 0) return 0; // m4.go:112,276: nothing inserted, nothing emitted
 
   int rc = ctx_reserve(c, (size_t)c->hist_len + n);
@@ -787,6 +836,7 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   J.start = (uint32_t)c->hist_len;
   J.len = (uint32_t)(c->hist_len + (int64_t)n);
   J.seed_prev = seed_prev_distance;
+  J.k1_flags = kJobLoadTable | kJobStoreTable;
   HIP_TRY(hipMemcpyAsync(c->d_job, &J, sizeof(Job), hipMemcpyHostToDevice, c->st));
   HIP_TRY(hipMemsetAsync(c->d_counts, 0, 8, c->st));
   // positions in [start, len-7) that K1 does not visit keep chain = 0 only if
@@ -809,6 +859,214 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
     HIP_TRY(hipStreamSynchronize(c->st));
     std::memcpy(out, c->h_recs, (size_t)cnt * sizeof(m4g_match));
   }
+  return (int64_t)cnt;
+}
+
+// ---------------------------------------------------------------------------
+// Block-parallel streaming: the result of calling m4g_find_matches on
+// consecutive blocks of `block_size` bytes (dst empty each time, as
+// matchfinder.Writer does, matchfinder.go:81-87), computed in one launch.
+// Each block's parse starts from a fresh matchEmitter, so given the chain
+// array the blocks are independent jobs; K1 builds the chain in segments, each
+// primed with the MaxDistance bytes before it (kernels.h, StreamInfo).
+// ---------------------------------------------------------------------------
+extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_size,
+                                           m4g_match *out, size_t out_cap, uint64_t *block_off) {
+  if (!c || (!src && n) || (!out && out_cap) || block_size == 0)
+    return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
+  const Params &p = c->p;
+  if ((uint64_t)c->hist_len + n >= ((uint64_t)1 << 31))
+    return fail(M4G_ERR_TOO_LARGE, "history + data must stay below 2^31 bytes");
+  const size_t nblocks = (n + block_size - 1) / block_size;
+  size_t need = 0;
+  for (size_t b = 0; b < nblocks; b++)
+    need += std::min(block_size, n - b * block_size) / (size_t)p.min_length + 2;
+  if (out_cap < need && n != 0) {
+    g_last_error = "out_cap below the sum of len/min_length + 2 over the blocks";
+    return -(int64_t)need;
+  }
+  if (block_off) block_off[0] = 0;
+  if (n == 0) return 0;
+
+  // The one-launch path needs: more than one block, at most one block end and
+  // one slide per K1 tile, and a bounded slide list.  Otherwise: block by block.
+  const uint64_t W = (uint64_t)p.max_distance;
+  const bool fast = nblocks >= 2 && block_size >= (size_t)K1_SUB + 7 && W >= (uint64_t)K1_SUB &&
+                    n / W + 2 < (size_t)kStreamMaxSlides && nblocks < ((size_t)1 << 24);
+  if (!fast) {
+    int64_t total = 0;
+    for (size_t b = 0; b < nblocks; b++) {
+      const size_t len = std::min(block_size, n - b * block_size);
+      int64_t r = m4g_find_matches(c, src + b * block_size, len, 0, out + total, out_cap - (size_t)total);
+      if (r < 0) return r;
+      total += r;
+      if (block_off) block_off[b + 1] = (uint64_t)total;
+    }
+    return total;
+  }
+
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ctx_slide(c);
+  if (rc) return rc;
+  const uint64_t x0 = (uint64_t)c->hist_len, x_end = x0 + n;
+  if ((rc = ctx_reserve(c, (size_t)x_end))) return rc;
+
+  // slide schedule of the equivalent call sequence (m4.go:82-99)
+  StreamInfo si{};
+  si.x0 = (uint32_t)x0;
+  si.x_end = (uint32_t)x_end;
+  si.block_size = (uint32_t)block_size;
+  si.nbp = 1;
+  si.bp_x[0] = 0;
+  si.bp_org[0] = 0;
+  uint64_t org = 0;
+  std::vector<Job> jobs; // segments first, then blocks
+  std::vector<uint64_t> block_org(nblocks);
+  for (size_t b = 0; b < nblocks; b++) {
+    const uint64_t xb = x0 + b * block_size;
+    if (b > 0 && xb - org > 2 * W) { // len(history) > 2*MaxDistance at the start of this call
+      org = xb - W;
+      si.bp_x[si.nbp] = (uint32_t)xb;
+      si.bp_org[si.nbp] = (uint32_t)org;
+      si.nbp++;
+    }
+    block_org[b] = org;
+  }
+  si.final_org = (uint32_t)org;
+
+  // K1 segments: the first one continues the handle's table and covers at
+  // least MaxDistance bytes, so every later segment primes from this call's data
+  const uint64_t S = std::max<uint64_t>(256u << 10, std::min<uint64_t>(4u << 20, (n + 63) / 64));
+  uint64_t a = x0;
+  while (a < x_end) {
+    uint64_t e = a == x0 ? std::min(x_end, x0 + std::max(W, S)) : std::min(x_end, a + S);
+    if (x_end - e < S / 4) e = x_end; // no tiny tail segment
+    Job J{};
+    J.src_off = 0;
+    J.chain_off = 0;
+    J.start = (uint32_t)(a == x0 ? x0 : a - W);
+    J.len = (uint32_t)(e + 7); // K1 inserts positions below len - 7 (block ends are skipped by rule)
+    J.store_from = (uint32_t)a;
+    J.k1_flags = (a == x0 ? kJobLoadTable : 0u) | (e == x_end ? kJobStoreTable : 0u);
+    jobs.push_back(J);
+    a = e;
+  }
+  const size_t nseg = jobs.size();
+  if (std::getenv("M4G_TRACE"))
+    std::fprintf(stderr, "[m4g] blocks: one launch, %zu K1 segments, %zu blocks, %u slides\n", nseg, nblocks,
+                 si.nbp - 1);
+  for (size_t b = 0; b < nblocks; b++) {
+    const uint64_t xb = x0 + b * block_size, xe = std::min(x_end, xb + block_size);
+    Job J{};
+    J.src_off = block_org[b];
+    J.chain_off = block_org[b];
+    J.start = (uint32_t)(xb - block_org[b]);
+    J.len = (uint32_t)(xe - block_org[b]);
+    jobs.push_back(J);
+  }
+
+  // workspace
+  if (c->wb_jobs < nblocks || c->wb_bytes < block_size) {
+    const size_t nj = std::max(nblocks, c->wb_jobs), nb = std::max(block_size, c->wb_bytes);
+    c->wb_jobs = c->wb_bytes = 0;
+    if ((rc = spec_alloc(c->wb, p, nj, nb))) return rc;
+    (void)hipFree(c->d_bcounts);
+    (void)hipFree(c->d_boff);
+    c->d_bcounts = nullptr;
+    c->d_boff = nullptr;
+    if (hipMalloc(&c->d_bcounts, nj * 4) != hipSuccess || hipMalloc(&c->d_boff, (nj + 1) * 8) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "allocating the per-block counters failed");
+    c->wb_jobs = nj;
+    c->wb_bytes = nb;
+  }
+  if (c->bjobs_cap < jobs.size()) {
+    (void)hipFree(c->d_bjobs);
+    c->d_bjobs = nullptr;
+    c->bjobs_cap = 0;
+    if (hipMalloc(&c->d_bjobs, jobs.size() * sizeof(Job)) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "allocating the job list failed");
+    c->bjobs_cap = jobs.size();
+  }
+  if (!c->d_si && hipMalloc(&c->d_si, sizeof(StreamInfo)) != hipSuccess)
+    return fail(M4G_ERR_NO_MEMORY, "allocating the stream descriptor failed");
+  if (!c->d_table2 && hipMalloc(&c->d_table2, ((size_t)1 << p.table_bits) * 4) != hipSuccess)
+    return fail(M4G_ERR_NO_MEMORY, "allocating the second table failed");
+  if (c->out_cap < need) {
+    (void)hipFree(c->d_out);
+    c->d_out = nullptr;
+    if (c->h_recs) (void)hipHostFree(c->h_recs);
+    c->h_recs = nullptr;
+    c->out_cap = 0;
+    if (hipMalloc(&c->d_out, need * sizeof(m4g_match)) != hipSuccess ||
+        hipHostMalloc(&c->h_recs, need * sizeof(m4g_match), hipHostMallocDefault) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "allocating the match buffers failed");
+    c->out_cap = need;
+  }
+
+  Trace tr;
+  // m4.go:101-107: append src; chain entries of never-inserted positions stay 0
+  HIP_TRY(hipMemcpyAsync(c->d_hist + x0, src, n, hipMemcpyHostToDevice, c->st));
+  HIP_TRY(hipMemsetAsync(c->d_chain + x0, 0, n * 4, c->st));
+  HIP_TRY(hipMemcpyAsync(c->d_bjobs, jobs.data(), jobs.size() * sizeof(Job), hipMemcpyHostToDevice, c->st));
+  HIP_TRY(hipMemcpyAsync(c->d_si, &si, sizeof(si), hipMemcpyHostToDevice, c->st));
+  HIP_TRY(hipMemsetAsync(c->d_counts, 0, 8, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st)); // jobs / si are stack and vector memory
+  tr.mark("blocks: H2D");
+
+  if ((rc = launch_k1(p, c->d_hist, x_end, (uint32_t)x_end, c->d_chain, c->d_bjobs, c->d_table, (int)nseg,
+                      c->st, c->d_si, c->d_table2)))
+    return rc;
+  std::swap(c->d_table, c->d_table2);
+  const Job *d_blocks = c->d_bjobs + nseg;
+  if ((rc = launch_parse(p, c->d_hist, x_end, c->d_chain, d_blocks, (int)nblocks, c->wb, c->d_bcounts,
+                         c->d_counts + 1, c->st)))
+    return rc;
+  if ((rc = launch_compact(c->wb, d_blocks, c->d_bcounts, (int)nblocks, c->d_boff, c->d_out, c->out_cap, c->st)))
+    return rc;
+
+  std::vector<uint64_t> off(nblocks + 1);
+  HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipMemcpyAsync(off.data(), c->d_boff, (nblocks + 1) * 8, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  tr.mark("blocks: kernels");
+
+  // the handle continues as after the last block's call: history = buffer from the final origin on
+  const uint64_t new_len = x_end - org;
+  if (org > 0) {
+    if (org >= new_len) {
+      HIP_TRY(hipMemcpyAsync(c->d_hist, c->d_hist + org, new_len, hipMemcpyDeviceToDevice, c->st));
+      HIP_TRY(hipMemcpyAsync(c->d_chain, c->d_chain + org, new_len * 4, hipMemcpyDeviceToDevice, c->st));
+    } else { // overlapping ranges: through a scratch buffer
+      if (c->tmp_cap < new_len * 4) {
+        (void)hipFree(c->d_tmp);
+        c->d_tmp = nullptr;
+        c->tmp_cap = 0;
+        if (hipMalloc(&c->d_tmp, new_len * 4) != hipSuccess)
+          return fail(M4G_ERR_NO_MEMORY, "allocating the history scratch failed");
+        c->tmp_cap = new_len * 4;
+      }
+      HIP_TRY(hipMemcpyAsync(c->d_tmp, c->d_hist + org, new_len, hipMemcpyDeviceToDevice, c->st));
+      HIP_TRY(hipMemcpyAsync(c->d_hist, c->d_tmp, new_len, hipMemcpyDeviceToDevice, c->st));
+      HIP_TRY(hipMemcpyAsync(c->d_tmp, c->d_chain + org, new_len * 4, hipMemcpyDeviceToDevice, c->st));
+      HIP_TRY(hipMemcpyAsync(c->d_chain, c->d_tmp, new_len * 4, hipMemcpyDeviceToDevice, c->st));
+    }
+  }
+  c->hist_len = (int64_t)new_len;
+
+  if (c->h_counts[1] & 1u) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+  if (c->h_counts[1] & 2u) return fail(M4G_ERR_HIP, "internal: parse slot overflow");
+  const uint64_t cnt = off[nblocks];
+  if (cnt > c->out_cap || cnt > out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
+  if (cnt) {
+    HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_out, (size_t)cnt * sizeof(m4g_match), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    std::memcpy(out, c->h_recs, (size_t)cnt * sizeof(m4g_match));
+  } else {
+    HIP_TRY(hipStreamSynchronize(c->st));
+  }
+  tr.mark("blocks: D2H + copy");
+  if (block_off)
+    for (size_t b = 0; b <= nblocks; b++) block_off[b] = off[b];
   return (int64_t)cnt;
 }
 

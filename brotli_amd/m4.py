@@ -33,7 +33,8 @@ class Params(ctypes.Structure):
 
 EXPORTS = [
     "m4g_strerror", "m4g_last_error", "m4g_device_count", "m4g_create", "m4g_destroy",
-    "m4g_reset", "m4g_find_matches", "m4g_debug_dump_tables", "m4g_history_len",
+    "m4g_reset", "m4g_find_matches", "m4g_find_matches_blocks", "m4g_debug_dump_tables",
+    "m4g_history_len",
     "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
 ]
@@ -76,6 +77,8 @@ def lib():
         L.m4g_find_matches.argtypes = [vp, vp, sz, ctypes.c_uint32, vp, sz]
         L.m4g_find_matches.restype = ctypes.c_int64
         L.m4g_debug_dump_tables.argtypes = [vp, vp, vp, sz]
+        L.m4g_find_matches_blocks.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp, ctypes.c_size_t, vp]
+        L.m4g_find_matches_blocks.restype = ctypes.c_int64
         L.m4g_history_len.argtypes = [vp]
         L.m4g_history_len.restype = ctypes.c_int64
         L.m4g_batch_create.argtypes = [ctypes.POINTER(Params), ctypes.c_int, sz, sz,
@@ -168,6 +171,26 @@ class M4:
         if r < 0:
             raise M4GError(f"m4g_find_matches: out_cap too small, need {-r}")
         return out[:r].copy()
+
+    def history_len(self) -> int:
+        """len(M4.history) after the last call."""
+        return int(lib().m4g_history_len(self._handle()))
+
+    def find_matches_blocks(self, src, block_size: int):
+        """FindMatches on every consecutive block of src in one launch
+        (m4g_find_matches_blocks); returns (matches[M,3], block_off[nblocks+1])."""
+        a = _as_u8(src)
+        min_len = self.MinLength or 4
+        nblocks = (a.size + block_size - 1) // block_size
+        cap = sum(min(block_size, a.size - b * block_size) // min_len + 2 for b in range(nblocks)) + 1
+        out = np.empty((cap, 3), dtype=np.uint32)
+        off = np.zeros(nblocks + 1, dtype=np.uint64)
+        r = lib().m4g_find_matches_blocks(self._handle(), a.ctypes.data if a.size else None, a.size,
+                                          block_size, out.ctypes.data, cap, off.ctypes.data)
+        _check(r, "m4g_find_matches_blocks")
+        if r < 0:
+            raise M4GError(f"m4g_find_matches_blocks: out_cap too small, need {-r}")
+        return out[:r], off
 
     def FindMatches(self, dst: List[Match], src) -> List[Match]:
         """matchfinder.MatchFinder.FindMatches: append to dst, return dst."""

@@ -109,6 +109,24 @@ int64_t m4g_find_matches(m4g_ctx *ctx, const uint8_t *src, size_t n,
                          uint32_t seed_prev_distance, m4g_match *out,
                          size_t out_cap);
 
+/* Block-parallel streaming -- SURVEY.md section 8(f).1.  Same result, and
+ * same handle state afterwards, as calling m4g_find_matches(ctx, block_b, len_b,
+ * 0, ...) for the consecutive blocks of `block_size` bytes of src (the last
+ * one may be shorter): what matchfinder.Writer.writeBlock does block after
+ * block with an empty dst (matchfinder/matchfinder.go:81-87, 59-79), including
+ * the history slide schedule (m4.go:82-99) and the seven uninserted positions at
+ * every block end (m4.go:112).  All blocks are processed in one launch.
+ * out receives the concatenated Match lists, block_off (nullable, nblocks+1
+ * entries) the start of each block's list.  Returns the total count, or
+ * -(needed capacity) when out_cap is below the sum of len_b/min_length + 2
+ * (handle unchanged), or an M4G_ERR_* code.  After this call
+ * m4g_debug_dump_tables may show empty table entries where the sequential
+ * calls would hold positions further back than MaxDistance; no result
+ * depends on those. */
+int64_t m4g_find_matches_blocks(m4g_ctx *ctx, const uint8_t *src, size_t n,
+                                size_t block_size, m4g_match *out,
+                                size_t out_cap, uint64_t *block_off);
+
 /* Debug / parity: copy the handle's hash table (1<<table_bits entries) and
  * chain deltas (one per history byte; reference keeps them only when
  * ChainLength > 0, this implementation always) to host memory.  Either

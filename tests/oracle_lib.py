@@ -106,6 +106,9 @@ class OracleM4:
             raise RuntimeError("oracle: out_cap too small (state already advanced)")
         return out[:r].copy()
 
+    def history_len(self) -> int:
+        return int(lib().m4ref_history_len(self._h))
+
     def dump_table(self) -> np.ndarray:
         tb = self.params[3] or 17
         out = np.zeros(1 << tb, dtype=np.uint32)

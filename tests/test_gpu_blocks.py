@@ -1,0 +1,68 @@
+"""m4g_find_matches_blocks: all blocks of one stream in one launch must equal
+block-after-block FindMatches calls on one M4 (what matchfinder.Writer does,
+matchfinder.go:59-93), including slides, the uninserted block tails and the
+state the handle is left in."""
+import numpy as np
+import pytest
+
+from brotli_amd import m4, synth
+from oracle_lib import OracleM4
+
+pytestmark = pytest.mark.gpu
+
+
+def same(got, ref):
+    return got.shape == ref.shape and (got == ref).all()
+
+
+def oracle_blocks(o, data, block):
+    lists = []
+    for p in range(0, len(data), block):
+        lists.append(o.FindMatches(data[p:p + block]))
+    return lists
+
+
+CASES = [
+    # (params, stream bytes, block size, bytes fed block-by-block before the call)
+    (dict(MaxDistance=1 << 16, DistanceBitCost=66), 1 << 20, 1 << 14, 0),          # many slides
+    (dict(MaxDistance=1 << 16, DistanceBitCost=66), 700001, 20000, 150000),        # prior history, ragged end
+    (dict(MaxDistance=1 << 18, DistanceBitCost=66), 3 << 20, 1 << 16, 0),          # Writer default block
+    (dict(MaxDistance=1 << 20, DistanceBitCost=66), 6 << 20, 1 << 16, 70000),      # params G, slide at 2 MiB
+    (dict(MaxDistance=1 << 16, ChainLength=8, HashLen=5, DistanceBitCost=66), 900000, 1 << 15, 40000),
+    (dict(MaxDistance=50000, MinLength=5, ChainLength=2, TableBits=14), 400000, 5000, 123456),
+    (dict(MaxDistance=1 << 18, DistanceBitCost=66), 100000, 1 << 20, 0),           # one block: per-block path
+    (dict(MaxDistance=1 << 18, DistanceBitCost=66), 50000, 1000, 0),               # small blocks: per-block path
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("kind", ["text", "log"])
+def test_blocks_equal_sequential_calls(case, kind):
+    kw, n, block, pre = CASES[case]
+    data = synth.text(pre + n + 50000, 77 + case) if kind == "text" else synth.log(pre + n + 50000, 77 + case)
+    g, o = m4.M4(**kw), OracleM4(**kw)
+    # history from earlier, ordinary calls
+    for p in range(0, pre, 30000):
+        blk = data[p:min(pre, p + 30000)]
+        assert same(g.find_matches(blk), o.FindMatches(blk))
+    got, off = g.find_matches_blocks(data[pre:pre + n], block)
+    ref = oracle_blocks(o, data[pre:pre + n], block)
+    assert len(off) == len(ref) + 1
+    for b, r in enumerate(ref):
+        assert same(got[int(off[b]):int(off[b + 1])], r), f"block {b} of {len(ref)}"
+    assert g.history_len() == o.history_len()
+    # the handle goes on exactly like the reference's
+    tail = data[pre + n:]
+    assert same(g.find_matches(tail[:20000]), o.FindMatches(tail[:20000]))
+    got2, off2 = g.find_matches_blocks(tail[20000:], 10000)
+    for b, r in enumerate(oracle_blocks(o, tail[20000:], 10000)):
+        assert same(got2[int(off2[b]):int(off2[b + 1])], r), f"second call, block {b}"
+
+
+def test_blocks_degenerate_inputs():
+    kw = dict(MaxDistance=1 << 16, DistanceBitCost=66)
+    for data in (bytes(300000), b"ab" * 150000, (b"0123456789" * 50 + b"xyz") * 700):
+        g, o = m4.M4(**kw), OracleM4(**kw)
+        got, off = g.find_matches_blocks(data, 8192)
+        for b, r in enumerate(oracle_blocks(o, data, 8192)):
+            assert same(got[int(off[b]):int(off[b + 1])], r), f"block {b}"
