@@ -235,11 +235,15 @@ class Writer:
     object with Encode(src, matches, last_block) -> bytes and Reset(); the
     bit-stream encoder stays on the CPU and is not part of this package."""
 
-    def __init__(self, Dest, MatchFinder, Encoder, BlockSize: int = 0):
+    def __init__(self, Dest, MatchFinder, Encoder, BlockSize: int = 0, BlocksPerLaunch: int = 1):
+        """BlocksPerLaunch > 1 (not in the reference): full blocks are collected and
+        match-found together with M4.find_matches_blocks, then encoded in order.
+        The output stream is the same; only the latency of Write changes."""
         self.Dest = Dest
         self.MatchFinder = MatchFinder
         self.Encoder = Encoder
         self.BlockSize = BlockSize
+        self.BlocksPerLaunch = BlocksPerLaunch
         self._in = bytearray()
 
     def Write(self, p) -> int:
@@ -249,12 +253,24 @@ class Writer:
             return len(p)
         self._in += p
         pos = 0
-        while pos + self.BlockSize <= len(self._in):
-            self._write_block(bytes(self._in[pos:pos + self.BlockSize]), False)
-            pos += self.BlockSize
+        if self.BlocksPerLaunch > 1 and hasattr(self.MatchFinder, "find_matches_blocks"):
+            span = self.BlockSize * self.BlocksPerLaunch
+            while pos + span <= len(self._in):
+                self._write_blocks(bytes(self._in[pos:pos + span]))
+                pos += span
+        else:
+            while pos + self.BlockSize <= len(self._in):
+                self._write_block(bytes(self._in[pos:pos + self.BlockSize]), False)
+                pos += self.BlockSize
         if pos:
             del self._in[:pos]
         return len(p)
+
+    def _write_blocks(self, p: bytes):
+        m, off = self.MatchFinder.find_matches_blocks(p, self.BlockSize)
+        for b in range(len(off) - 1):
+            blk = p[b * self.BlockSize:(b + 1) * self.BlockSize]
+            self.Dest.write(self.Encoder.Encode(blk, m[int(off[b]):int(off[b + 1])], False))
 
     def _write_block(self, p: bytes, last: bool):
         matches = self.MatchFinder.FindMatches([], p)
@@ -262,6 +278,13 @@ class Writer:
         self.Dest.write(self.Encoder.Encode(p, m, last))
 
     def Close(self):
+        full = len(self._in) // self.BlockSize * self.BlockSize if self.BlockSize else 0
+        if full and self.BlocksPerLaunch > 1 and hasattr(self.MatchFinder, "find_matches_blocks"):
+            self._write_blocks(bytes(self._in[:full]))
+            del self._in[:full]
+        while self.BlockSize and len(self._in) >= self.BlockSize:  # cannot happen after Write; kept for safety
+            self._write_block(bytes(self._in[:self.BlockSize]), False)
+            del self._in[:self.BlockSize]
         self._write_block(bytes(self._in), True)
         self._in.clear()
 

@@ -12,6 +12,7 @@
 //   matchfinder.Writer       matchfinder/matchfinder.go:44-103
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -65,6 +66,32 @@ public:
   }
   void Reset() override {
     if (ctx_) check(m4g_reset(ctx_), "m4g_reset");
+  }
+
+  // Not in the reference: FindMatches(nil, block) for every consecutive block of
+  // `blockSize` bytes of src in one GPU launch (m4g_find_matches_blocks).  The
+  // Match list of block b is dst[blockOff[b] .. blockOff[b+1]) (appended to dst).
+  std::vector<Match> &FindMatchesBlocks(std::vector<Match> &dst, const uint8_t *src, size_t n,
+                                        size_t blockSize, std::vector<size_t> &blockOff) {
+    if (!ctx_) {
+      m4g_params p{MaxDistance, MinLength, HashLen, TableBits, ChainLength, DistanceBitCost};
+      check(m4g_create(&p, Device, &ctx_), "m4g_create");
+    }
+    const size_t minLen = (size_t)(MinLength ? MinLength : 4);
+    const size_t nblocks = blockSize ? (n + blockSize - 1) / blockSize : 0;
+    size_t cap = 0;
+    for (size_t b = 0; b < nblocks; b++) cap += std::min(blockSize, n - b * blockSize) / minLen + 2;
+    if (buf_.size() < cap) buf_.resize(cap);
+    std::vector<uint64_t> off(nblocks + 1, 0);
+    const int64_t r = m4g_find_matches_blocks(ctx_, src, n, blockSize, buf_.data(), buf_.size(), off.data());
+    check(r, "m4g_find_matches_blocks");
+    const size_t base = dst.size();
+    dst.reserve(base + (size_t)r);
+    for (int64_t k = 0; k < r; k++)
+      dst.push_back(Match{buf_[k].unmatched, buf_[k].length, buf_[k].distance});
+    blockOff.assign(nblocks + 1, base);
+    for (size_t b = 0; b <= nblocks; b++) blockOff[b] = base + (size_t)off[b];
+    return dst;
   }
 
 private:

@@ -18,6 +18,30 @@ int main() {
     std::puts("FAIL");
     return 1;
   }
+  // block-parallel call: 4 blocks of 8 KiB of a periodic text; every block after
+  // the first finds its content one block back
+  std::vector<uint8_t> data(4 * 8192);
+  for (size_t i = 0; i < data.size(); i++) data[i] = (uint8_t)("the quick brown fox "[i % 20] + (i % 8192) / 1024);
+  matchfinder::M4 mb;
+  std::vector<matchfinder::Match> all;
+  std::vector<size_t> off;
+  mb.FindMatchesBlocks(all, data.data(), data.size(), 8192, off);
+  matchfinder::M4 ms;
+  for (size_t b = 0; b < 4; b++) {
+    std::vector<matchfinder::Match> one;
+    ms.FindMatches(one, data.data() + b * 8192, 8192);
+    if (off[b + 1] - off[b] != one.size()) {
+      std::puts("FAIL blocks (count)");
+      return 1;
+    }
+    for (size_t k = 0; k < one.size(); k++) {
+      const matchfinder::Match &x = all[off[b] + k];
+      if (x.Unmatched != one[k].Unmatched || x.Length != one[k].Length || x.Distance != one[k].Distance) {
+        std::puts("FAIL blocks (match)");
+        return 1;
+      }
+    }
+  }
   std::puts("ok");
   return 0;
 }

@@ -66,3 +66,24 @@ def test_blocks_degenerate_inputs():
         got, off = g.find_matches_blocks(data, 8192)
         for b, r in enumerate(oracle_blocks(o, data, 8192)):
             assert same(got[int(off[b]):int(off[b + 1])], r), f"block {b}"
+
+
+def test_writer_blocks_per_launch_same_stream():
+    """matchfinder.Writer over the GPU handle with many blocks per launch writes
+    the byte-identical stream the block-by-block Writer writes, and it decodes."""
+    import io
+    from oracle_lib import OracleEncoder, brotli_decompress
+    kw = dict(MaxDistance=1 << 18, DistanceBitCost=66)
+    data = synth.text(3 * (1 << 20) + 12345, 5)
+    bufs = []
+    for per_launch in (1, 16):
+        buf = io.BytesIO()
+        w = m4.Writer(buf, m4.M4(**kw), OracleEncoder(), BlockSize=1 << 16, BlocksPerLaunch=per_launch)
+        for p in range(0, len(data), 300000):  # ragged Write sizes
+            w.Write(data[p:p + 300000])
+        w.Close()
+        bufs.append(buf.getvalue())
+    assert bufs[0] == bufs[1]
+    ref_stream, _ = OracleM4(**kw).compress(data, 1 << 16)
+    assert bufs[1] == ref_stream
+    assert brotli_decompress(bufs[1], len(data)) == data
