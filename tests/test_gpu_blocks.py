@@ -87,3 +87,23 @@ def test_writer_blocks_per_launch_same_stream():
     ref_stream, _ = OracleM4(**kw).compress(data, 1 << 16)
     assert bufs[1] == ref_stream
     assert brotli_decompress(bufs[1], len(data)) == data
+
+
+def test_blocks_largest_window_slide():
+    """BASELINE config 4's streaming shape: one 48 MiB stream in 1 MiB blocks with
+    the largest window the V2 header allows (MaxDistance 16777200), so the slide at
+    len(history) > 32 MiB fires inside the launch.  ChainLength 2 instead of 64
+    keeps the CPU oracle to seconds; the chain-walk itself is covered at full
+    depth by the batch tests."""
+    kw = dict(MaxDistance=16777200, ChainLength=2, HashLen=5, DistanceBitCost=66)
+    n, block = 48 << 20, 1 << 20
+    host = np.empty(n, dtype=np.uint8)
+    synth.fill(host, 1 << 20, 900, "text", 8)
+    g, o = m4.M4(**kw), OracleM4(**kw)
+    got, off = g.find_matches_blocks(host, block)
+    for b in range(n // block):
+        ref = o.FindMatches(host[b * block:(b + 1) * block])
+        assert same(got[int(off[b]):int(off[b + 1])], ref), f"block {b}"
+    assert g.history_len() == o.history_len()
+    tail = synth.text(100000, 3)
+    assert same(g.find_matches(tail), o.FindMatches(tail))
