@@ -224,7 +224,7 @@ __device__ __forceinline__ uint32_t k1_sort64(uint32_t K, uint32_t lane, const K
 
 // Owner wave: sort NJ*64 keys, link equal hashes, read / update the table
 // slice, leave the chain entries in res[] (indexed by tile position).
-template <int NJ>
+template <int NJ, bool STREAM>
 __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const uint8_t *runlen8,
                                            const uint32_t *myq, uint32_t n, uint32_t sb,
                                            uint32_t lane, uint32_t cb, const K1SortAddr &A,
@@ -269,12 +269,16 @@ __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const
     const bool tail = Kn == K1_KEY_INVALID || (Kn >> K1_KEY_IDX_SHIFT) != idxl;
     const uint32_t P = samep ? Vp : slice[idxl];
     // a predecessor at or below the buffer origin counts as "empty" (m4.go:152, 92-98)
-    const uint32_t pp = P >> cb, pos = sb + rel, org = pos >= org_next_x ? org_next : org_cur;
+    const uint32_t pp = P >> cb, pos = sb + rel, org = STREAM ? (pos >= org_next_x ? org_next : org_cur) : 0u;
     res[rel] = pp > org ? ((pos - pp) | ((P & cmask) == (K[j] & cmask) ? kChainMaybe : 0u)) : 0u;
     if (tail) slice[idxl] = V[j];
   }
 }
 
+// STREAM: the jobs are segments of one stream (StreamInfo *si is set): block
+// tails are skipped, origins move, priming positions get no chain entry.  The
+// batch instantiation folds all of that away.
+template <bool STREAM>
 __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
@@ -312,10 +316,10 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     table[k] = load_table ? table_io[(q << part_bits) + k] : 0u;
   if (tid < 2 * K1_WAVES + 2 + K1_PER) qn[tid] = 0; // fills and overflow flags
   // block structure of a stream handled in one launch (none: one block, origin 0)
-  const uint32_t st_x0 = si ? si->x0 : 0u, st_xend = si ? si->x_end : 0xFFFFFFFFu;
-  const uint32_t st_block = si ? si->block_size : 0u, st_nbp = si ? si->nbp : 1u;
+  const uint32_t st_x0 = STREAM ? si->x0 : 0u, st_xend = STREAM ? si->x_end : 0xFFFFFFFFu;
+  const uint32_t st_block = STREAM ? si->block_size : 0u, st_nbp = STREAM ? si->nbp : 1u;
   uint32_t bpi = 0; // breakpoint in force at the current tile
-  const uint32_t store_from = J.store_from;
+  const uint32_t store_from = STREAM ? J.store_from : 0u;
 
   // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces:
   // only the upper dword of the low 64 product bits is needed (table_bits <= 24)
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     uint32_t org_cur = 0, org_next_x = 0xFFFFFFFFu, org_next = 0;
     // end of the block the tile starts in: its last 7 positions are not inserted
     uint32_t blk_end = 0xFFFFFFFFu;
-    if (si) {
+    if (STREAM) {
       while (bpi + 1 < st_nbp && si->bp_x[bpi + 1] <= sb) bpi++;
       org_cur = si->bp_org[bpi];
       if (bpi + 1 < st_nbp) {
@@ -381,7 +385,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
         const uint32_t lo = v[w].x & mask_lo, hi = v[w].y & mask_hi;
         const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
         const uint32_t pos = sb + rel;
-        const bool in = pos < end && (h >> part_bits) == q && !(pos + 7 >= blk_end && pos < blk_end);
+        const bool in = pos < end && (h >> part_bits) == q &&
+                        !(STREAM && pos + 7 >= blk_end && pos < blk_end);
         // check bits of the first 4 bytes (top bits of a multiplicative hash)
         const uint32_t ck = cb ? (v[w].x * 0x9E3779B1u) >> (32 - cb) : 0u;
         // run folding: this position continues the previous one (lane - 1) when
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
         if (in && !same) heads |= 1u << w;
         if (cont != 0) { // wave-uniform: some run in this window
           if (same && store_interior && !(dbg & 1) && pos >= store_from) // predecessor at the origin = "empty"
-            chain[pos] = pos - 1 > (pos >= org_next_x ? org_next : org_cur) ? (1u | kChainMaybe) : 0u;
+            chain[pos] = pos - 1 > (STREAM && pos >= org_next_x ? org_next : org_cur) ? (1u | kChainMaybe) : 0u;
           uint32_t runlen1 = 0; // run length - 1
           if (lane < 63) runlen1 = (uint32_t)__builtin_ctzll(~(cont >> (lane + 1)));
           if ((heads >> w & 1) && runlen1) {
@@ -421,9 +426,9 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
       if (n == 0) return;
       uint32_t *slice = table + (wave << own_shift);
       if (n <= 64)
-        k1_consume<1>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA, org_cur, org_next_x, org_next);
+        k1_consume<1, STREAM>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA, org_cur, org_next_x, org_next);
       else
-        k1_consume<2>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA, org_cur, org_next_x, org_next);
+        k1_consume<2, STREAM>(slice, res, runlen8, queues + wave * K1_QCAP, n, sb, lane, cb, SA, org_cur, org_next_x, org_next);
     };
 
     const uint32_t headmask = produce(std::integral_constant<int, K1_PER>{}, 0, true, &ovf[par]);
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   }
 
   if (store_table) { // entries relative to the origin after the call, at or below it = empty
-    const uint32_t rebase = si ? si->final_org : 0u;
+    const uint32_t rebase = STREAM ? si->final_org : 0u;
     lds_barrier();
     for (uint32_t k = tid; k < part_size; k += K1_THREADS) {
       const uint32_t v = table[k];
