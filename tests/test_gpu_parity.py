@@ -148,6 +148,23 @@ def test_batch_histograms_edge_inputs(kw):
         assert (histos[c, 960:] == dist).all(), f"{name}: distance histogram"
 
 
+def test_batch_host_api_sharded_over_device_list():
+    """m4g_find_matches_batch with several entries in `devices` (chunk c goes to
+    devices[c % n]): the one GPU of the test box listed three times
+    exercises the sharding, the per-device offsets and the ordered concatenation
+    exactly as three GPUs would."""
+    sizes = [70001, 0, 1 << 16, 12345, 200000, 8, 99999, 31, 150000, 5]
+    blob = b"".join(synth.text(s, 300 + i) if i % 2 else synth.log(s, 300 + i) for i, s in enumerate(sizes))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    one = m4.find_matches_batch(blob, off, (0,), True, **PARAMS_G)
+    three = m4.find_matches_batch(blob, off, (0, 0, 0), True, **PARAMS_G)
+    assert (one[1] == three[1]).all() and same(one[0], three[0]) and (one[2] == three[2]).all()
+    for c, s in enumerate(sizes):
+        chunk = blob[int(off[c]):int(off[c + 1])]
+        ref = OracleM4(**PARAMS_G).FindMatches(chunk)
+        assert same(three[0][int(three[1][c]):int(three[1][c + 1])], ref), f"chunk {c}"
+
+
 def test_full_size_chunks_properties():
     """BASELINE config 2 shape (1 MiB chunks, params G): size-independent
     properties on every chunk + bit-exactness on a sample."""
