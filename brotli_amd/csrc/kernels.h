@@ -647,6 +647,19 @@ __device__ __forceinline__ uint64_t k3_wave_of_block(uint32_t b, uint32_t nblock
   return (uint64_t)g * group + xcd * wpj + slot;
 }
 
+// A speculative lane gives its block up when a match runs more than this far
+// past the block end: inside long repeats (zero pages, short periods) every
+// lane would otherwise extend the same match to the end of the buffer.  The
+// true parse usually has that match pending from an earlier block and skips
+// the block in O(1); where it does not, k3c redoes the block with a forward
+// extension that uses the whole wave.
+constexpr int32_t K3_EXT_LIMIT = 4096;
+
+// desc.out_off written by k3b, read by k3c
+constexpr uint32_t kStitchUnsynced = 0;   // whole block parsed from E[k-1], no common flush: ST + Tout hold the result
+constexpr uint32_t kStitchSynced = 1;     // joined the speculative records at keep_from
+constexpr uint32_t kStitchIncomplete = 2; // given up (entry state or this parse aborted): k3c parses the block
+
 __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     const uint8_t *__restrict__ src_base, uint64_t src_total,
     const uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, Rec *__restrict__ rs,
@@ -665,6 +678,8 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   const int32_t bb = block_begin(g, active ? (int32_t)k : 0);
   const int32_t be = block_end(g, active ? (int32_t)k : 0);
   const int32_t len = (int32_t)J.len;
+  // matches are followed at most K3_EXT_LIMIT past the block (see above)
+  const int32_t len_eff = (int64_t)be + K3_EXT_LIMIT < (int64_t)len ? be + K3_EXT_LIMIT : len;
 
   RecSink sink{rs + t * L.slot, 0, L.slot};
   ParseState S;
@@ -674,10 +689,11 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   M.chain = chain_base + J.chain_off;
   M.lsrc = lds_src + lane * K3_SRC_DW;
   M.lch = lds_ch + lane * K3_CH_DW;
+  bool aborted = false;
 
   for (int32_t e = 0; e < L.sub_block; e += K3_W) { // uniform trip count
     const int32_t w0 = bb + e;
-    const bool row_on = active && w0 < be;
+    const bool row_on = active && !aborted && w0 < be;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     k3_stage(src_base, (int64_t)src_total, chain_base, lds_src, lds_ch, lane, row_on,
@@ -687,11 +703,17 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (row_on) {
       M.w0 = w0;
-      parse_range<false>(M, len, P, S, min(w0 + K3_W, be), sink);
+      parse_range<false>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
+      aborted = len_eff < len && (S.error & kStateTouchedEnd);
     }
   }
   if (!active) return;
-  if (k == (uint32_t)g.nblocks - 1) parse_finish(len, P, S, sink);
+  if (aborted) {
+    S.error |= kStateAborted;
+    sink.n = 0;
+  } else if (k == (uint32_t)g.nblocks - 1) {
+    parse_finish(len, P, S, sink);
+  }
   E[t] = S;
   BlockDesc d;
   d.n_spec = sink.n;
@@ -700,10 +722,12 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   d.out_off = 0;
   desc[t] = d;
   if (sink.n > L.slot) atomicOr(errors, 2u);
-  if (S.error) atomicOr(errors, 1u);
+  // a range error of a speculative parse may come from its guessed state: only
+  // block 0, whose parse is the true one, reports here; k3b / k3c report theirs
+  if (k == 0 && !aborted && (S.error & kStateErrRange)) atomicOr(errors, 1u);
 }
 
-// desc.out_off doubles as the "synchronised" flag between k3b and k3c.
+// desc.out_off doubles as the k3b -> k3c status (kStitch*).
 __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, const Rec *__restrict__ rs, Rec *__restrict__ st,
@@ -721,21 +745,52 @@ __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
   RecSink sink{st + t * L.slot, 0, L.slot};
   ParseState T = E[t - 1];
   BlockDesc d = desc[t];
+  if (T.error & kStateAborted) { // no entry state to start from
+    d.n_stitch = 0;
+    d.keep_from = 0;
+    d.out_off = kStitchIncomplete;
+    desc[t] = d;
+    return;
+  }
+  T.error &= kStateErrRange;
+  const int32_t len = (int32_t)J.len, be = block_end(g, (int32_t)k);
+  const int32_t len_eff = (int64_t)be + K3_EXT_LIMIT < (int64_t)len ? be + K3_EXT_LIMIT : len;
   uint32_t keep = 0;
   GlobalMem M{src, chain};
-  const bool ok = stitch_block(M, (int32_t)J.len, P, g, (int32_t)k, rs + t * L.slot,
+  const bool ok = stitch_block(M, len_eff, P, g, (int32_t)k, rs + t * L.slot,
                                min(d.n_spec, L.slot), E[t], T, sink, keep);
+  const bool gave_up = len_eff < len && (T.error & kStateTouchedEnd);
   d.n_stitch = sink.n;
   d.keep_from = keep;
-  d.out_off = ok ? 1u : 0u;
+  d.out_off = gave_up ? kStitchIncomplete : (ok ? kStitchSynced : kStitchUnsynced);
   desc[t] = d;
-  if (!ok) Tout[t] = T;
+  if (!ok && !gave_up) Tout[t] = T;
   if (sink.n > L.slot) atomicOr(errors, 2u);
+}
+
+// Memory accessor for code that every lane of a wave runs in lockstep with
+// identical arguments (k3c): a long forward extension compares 64 x 8 bytes per
+// step instead of 8.
+struct WaveMem : GlobalMem {};
+__device__ __forceinline__ int32_t extend_fwd(const WaveMem &M, int32_t len, int32_t i, int32_t j) {
+  const int32_t lane = (int32_t)(threadIdx.x & 63);
+  while ((int64_t)j + 64 * 8 + 8 < (int64_t)len) {
+    const uint64_t a = M.ld64(i + 8 * lane), b = M.ld64(j + 8 * lane);
+    const unsigned long long ne = __ballot(a != b);
+    if (ne) {
+      const int l = __builtin_ctzll(ne);
+      const uint64_t x = (uint64_t)shfl64((int64_t)(a ^ b), l);
+      return j + 8 * l + (int32_t)(__builtin_ctzll(x) >> 3);
+    }
+    i += 64 * 8;
+    j += 64 * 8;
+  }
+  return extend_fwd(static_cast<const GlobalMem &>(M), len, i, j);
 }
 
 __global__ __launch_bounds__(64) void k3c_validate(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
-    const Job *__restrict__ jobs, const Rec *__restrict__ rs, Rec *__restrict__ st,
+    const Job *__restrict__ jobs, Rec *__restrict__ rs, Rec *__restrict__ st,
     const ParseState *__restrict__ E, const ParseState *__restrict__ Tout,
     BlockDesc *__restrict__ desc, uint32_t *__restrict__ counts, uint32_t *__restrict__ errors,
     int njobs, SpecLayout L, ParseParams P) {
@@ -748,20 +803,26 @@ __global__ __launch_bounds__(64) void k3c_validate(
   const uint64_t b0 = (uint64_t)job * L.kmax;
   const uint8_t *src = src_base + J.src_off;
   const uint32_t *chain = chain_base + J.chain_off;
+  const int32_t len = (int32_t)J.len;
 
-  uint32_t off = desc[b0].n_spec; // block 0: the speculative parse IS the true parse
-  if (lane == 0) desc[b0].out_off = 0;
-  uint32_t k = 1;
+  uint32_t off = 0, k = 1;
   bool valid = true;
-  ParseState T; // meaningful only while !valid
-  state_init(T, 0, 0);
+  ParseState T; // the true state entering block k; meaningful only while !valid
+  state_init(T, g.start, J.seed_prev);
   uint32_t err = 0;
+  if (E[b0].error & kStateAborted) { // even block 0 was given up: parse from the initial state
+    valid = false;
+    k = 0;
+  } else {
+    off = desc[b0].n_spec; // block 0: the speculative parse IS the true parse
+    if (lane == 0) desc[b0].out_off = 0;
+  }
   while (k < K) {
     if (valid) {
       const uint32_t kk = k + lane;
-      BlockDesc d{0, 0, 0, 1};
+      BlockDesc d{0, 0, 0, kStitchSynced};
       if (kk < K) d = desc[b0 + kk];
-      const unsigned long long bad = __ballot(kk < K && d.out_off == 0);
+      const unsigned long long bad = __ballot(kk < K && d.out_off != kStitchSynced);
       const uint32_t room = min(64u, K - k);
       const uint32_t ngood = bad ? min((uint32_t)__builtin_ctzll(bad), room) : room;
       uint32_t cnt = (uint32_t)lane < ngood ? d.n_stitch + (d.n_spec - d.keep_from) : 0;
@@ -774,25 +835,86 @@ __global__ __launch_bounds__(64) void k3c_validate(
       off += __shfl(incl, 63);
       k += ngood;
       if (bad && k < K) {
-        // block k did not synchronise, but it was entered in the right state:
-        // its stitch records are the true records of the whole block.
         const int bl = (int)ngood;
-        const uint32_t ns = __shfl(d.n_stitch, bl);
-        if (lane == bl) desc[b0 + k].out_off = off;
-        off += ns;
-        T = Tout[b0 + k];
+        const uint32_t status = __shfl(d.out_off, bl);
         valid = false;
-        k++;
+        if (status == kStitchUnsynced) {
+          // block k did not synchronise, but it was entered in the right state:
+          // its stitch records are the true records of the whole block.
+          const uint32_t ns = __shfl(d.n_stitch, bl);
+          if (lane == bl) desc[b0 + k].out_off = off;
+          off += ns;
+          T = Tout[b0 + k];
+          k++;
+        } else {
+          // the stitch of block k was given up: redo it below from the state
+          // its predecessor ended in, which is the true one (it synchronised)
+          T = E[b0 + k - 1];
+          T.error &= kStateErrRange;
+        }
       }
     } else {
-      // serial re-stitch of block k from the true state (uniform over lanes)
+      // block k from the true state T (every lane runs the same code)
       const uint64_t t = b0 + k;
-      RecSink sink{st + t * L.slot, 0, L.slot};
       const BlockDesc d = desc[t];
+      const ParseState Ek = E[t];
+      const int32_t bb = block_begin(g, (int32_t)k), be = block_end(g, (int32_t)k);
+      const uint32_t n_spec = min(d.n_spec, L.slot);
+      // Fast path.  T has nothing pending and stands at the block start, so it
+      // differs from the state the speculative parse assumed only in next_emit
+      // and in the repeat distance.  If no backward extension of the speculative
+      // parse ran into its assumed next_emit (kStateHitLo) and the repeat probe
+      // with T's distance fails (4-byte compare) at every position before the
+      // first speculative record ends, the true parse IS the speculative one:
+      // same records (the first one starts its literals at T.next_emit), same
+      // end state.
+      bool fast = T.m0.end == 0 && T.i == bb && T.next_emit <= bb &&
+                  !(Ek.error & (kStateAborted | kStateHitLo | kStateErrRange));
+      int32_t first_end = be; // positions below it are probed with T's distance
+      if (fast && n_spec) first_end = min(be, rec_end(rs[t * L.slot]));
+      if (fast && T.have_prev) {
+        bool hit = false;
+        for (int32_t i = bb + lane; i < first_end; i += 64) {
+          const int32_t p = i + 1, c = p - (int32_t)T.prev_dist;
+          if (c < 0 || p + 4 > len || ld32(src + c) == ld32(src + p)) hit = true;
+        }
+        if (__ballot(hit)) fast = false;
+      }
+      if (fast) {
+        if (n_spec && lane == 0) { // the first record's literals begin where T's do
+          Rec r = rs[t * L.slot];
+          const uint32_t flag = r.lit_start & kRecFlushBit;
+          r.unmatched += (r.lit_start & ~kRecFlushBit) - (uint32_t)T.next_emit;
+          r.lit_start = (uint32_t)T.next_emit | flag;
+          rs[t * L.slot] = r;
+        }
+        if (lane == 0) {
+          BlockDesc nd = d;
+          nd.n_stitch = 0;
+          nd.keep_from = 0;
+          nd.out_off = off;
+          desc[t] = nd;
+        }
+        off += n_spec;
+        const ParseState prevT = T;
+        T = Ek;
+        T.error = (Ek.error & kStateErrRange) | prevT.error;
+        if (n_spec == 0) { // nothing emitted: literals and repeat distance carry over
+          T.next_emit = prevT.next_emit;
+          T.have_prev = prevT.have_prev;
+          T.prev_dist = prevT.prev_dist;
+        } else {
+          valid = true; // E[k] is the true end state, so block k+1's stitch stands
+        }
+        k++;
+        continue;
+      }
+      RecSink sink{st + t * L.slot, 0, L.slot};
       uint32_t keep = 0;
-      GlobalMem M{src, chain};
-      const bool ok = stitch_block(M, (int32_t)J.len, P, g, (int32_t)k, rs + t * L.slot,
-                                   min(d.n_spec, L.slot), E[t], T, sink, keep);
+      WaveMem M;
+      M.src = src;
+      M.chain = chain;
+      const bool ok = stitch_block(M, len, P, g, (int32_t)k, rs + t * L.slot, n_spec, Ek, T, sink, keep);
       if (sink.n > L.slot) err |= 2u;
       if (lane == 0) {
         BlockDesc nd = d;
@@ -801,12 +923,12 @@ __global__ __launch_bounds__(64) void k3c_validate(
         nd.out_off = off;
         desc[t] = nd;
       }
-      off += sink.n + (d.n_spec - keep);
+      off += sink.n + (n_spec - keep);
       if (ok) valid = true;
       k++;
     }
   }
-  if (!valid && T.error) err |= 1u;
+  if (T.error & kStateErrRange) err |= 1u;
   if (lane == 0) {
     counts[job] = off;
     if (err) atomicOr(errors, err);

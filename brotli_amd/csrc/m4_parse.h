@@ -53,8 +53,16 @@ struct ParseState {
   int32_t next_emit;  // matchEmitter.NextEmit (emitter.go:24)
   uint32_t prev_dist; // e.Dst[len-1].Distance, valid iff have_prev
   uint32_t have_prev; // len(e.Dst) > 0
-  uint32_t error;     // 1: repeat distance reaches before buffer start
+  uint32_t error;     // kStateErrRange | diagnostic flags of the speculative parse (below)
 };
+// ParseState.error bits.  Only kStateErrRange is an error (the Go code would
+// panic); the others tell the speculative sub-block parse (m4_spec.h) what a
+// result depended on.
+constexpr uint32_t kStateErrRange = 1;   // repeat distance reaches before the buffer start
+constexpr uint32_t kStateHitLo = 4;      // before anything was emitted, a match started exactly at next_emit:
+                                         // its backward extension may have been cut short by that bound
+constexpr uint32_t kStateTouchedEnd = 8; // a match reached `len` (the caller may have passed a shortened len)
+constexpr uint32_t kStateAborted = 16;   // set by the kernels: the parse of this block was given up
 
 M4G_HD uint32_t ld32(const uint8_t *p) {
   uint32_t v;
@@ -304,7 +312,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     const uint64_t cf2 = M.far64(cand_fast2 ? cand + 8 : 0);
 
     // B. m4.go:128-138 repeat match one byte after the current position
-    if (probe_err) S.error = 1; // the Go code would panic on the slice bounds
+    if (probe_err) S.error |= kStateErrRange; // the Go code would panic on the slice bounds
     if (do_probe) {
       uint32_t cw;
       if (pc_off <= 4) {
@@ -317,9 +325,10 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
         cw = M.ld32(c);
       }
       AbsMatch m;
-      if (cw == M.ld32(p) && match_at(M, len, p, c, S.next_emit + 1, m) &&
-          m.end - m.start >= P.min_length)
-        S.m0 = m;
+      if (cw == M.ld32(p) && match_at(M, len, p, c, S.next_emit + 1, m)) {
+        if (m.end >= len) S.error |= kStateTouchedEnd;
+        if (m.end - m.start >= P.min_length) S.m0 = m;
+      }
     }
 
     // D. m4.go:149-151: a match set just now makes i an interior position
@@ -340,6 +349,10 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     if (ce & kChainMaybe) {
       const bool hit = cand_fast ? match_regs(M, len, i, cand, S.next_emit, cf, cf2, cand_fast2, cb, m)
                                  : match_at(M, len, i, cand, S.next_emit, m);
+      if (hit) {
+        if (!S.have_prev && m.start == S.next_emit) S.error |= kStateHitLo;
+        if (m.end >= len) S.error |= kStateTouchedEnd;
+      }
       if (hit && m.end - m.start > P.min_length) {
         int64_t sc = score(m, P.distance_bit_cost);
         if (sc > 0) {
@@ -356,6 +369,8 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       cand -= (int32_t)dd;
       if (i - cand > P.max_distance) break;
       if (match_at(M, len, i, cand, S.next_emit, m)) {
+        if (!S.have_prev && m.start == S.next_emit) S.error |= kStateHitLo;
+        if (m.end >= len) S.error |= kStateTouchedEnd;
         if (m.end - m.start > P.min_length) {
           int64_t sc = score(m, P.distance_bit_cost);
           if (sc > cur_score) {

@@ -100,9 +100,9 @@ M4G_HD bool stitch_block(const Mem &M, int32_t len, const ParseParams &P,
     }
   }
   if (synced) {
-    const uint32_t err = T.error;
+    const uint32_t err = T.error; // keep this parse's own flags, drop the speculative parse's diagnostics
     T = E;
-    T.error |= err;
+    T.error = (E.error & kStateErrRange) | err;
     keep_from = j + 1;
   } else {
     keep_from = n_spec;

@@ -55,7 +55,7 @@ int64_t sim_find_matches(const uint8_t *src, int32_t n, int max_distance, int mi
   if ((int64_t)sink.v.size() > out_cap) return -(int64_t)sink.v.size();
   for (auto &r : sink.v) r.lit_start &= ~kRecFlushBit;
   if (!sink.v.empty()) std::memcpy(out, sink.v.data(), sink.v.size() * sizeof(Rec));
-  return S.error ? INT64_MIN : (int64_t)sink.v.size();
+  return (S.error & m4g::kStateErrRange) ? INT64_MIN : (int64_t)sink.v.size();
 }
 
 #ifdef HAVE_SPEC
@@ -110,7 +110,7 @@ int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, i
   for (auto &r : result) r.lit_start &= ~kRecFlushBit;
   if ((int64_t)result.size() > out_cap) return -(int64_t)result.size();
   if (!result.empty()) std::memcpy(out, result.data(), result.size() * sizeof(Rec));
-  return T.error ? INT64_MIN : (int64_t)result.size();
+  return (T.error & m4g::kStateErrRange) ? INT64_MIN : (int64_t)result.size();
 }
 #endif
 }

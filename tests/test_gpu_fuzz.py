@@ -28,9 +28,17 @@ def random_params(rng):
 
 
 def random_input(rng, n):
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 8)
     if n == 0:
         return b""
+    if kind == 6:  # incompressible
+        return bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    if kind == 7:  # regions of different character, sharp transitions
+        out = bytearray()
+        while len(out) < n:
+            m = int(rng.integers(1, 30000))
+            out += random_input(rng, m) if rng.random() < 0.7 else bytes(m)
+        return bytes(out[:n])
     if kind == 0:  # small alphabet noise
         return bytes(rng.integers(0, int(rng.integers(2, 6)), n, dtype=np.uint8))
     if kind == 1:  # phrases from a small dictionary, with mutations

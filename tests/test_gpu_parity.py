@@ -165,6 +165,36 @@ def test_batch_host_api_sharded_over_device_list():
         assert same(three[0][int(three[1][c]):int(three[1][c + 1])], ref), f"chunk {c}"
 
 
+def test_batch_inputs_that_defeat_the_speculation():
+    """Inputs on which the sub-block speculation cannot synchronise through a
+    common flush: incompressible bytes (no matches at all), zero pages and short
+    periods (one match spanning many sub-blocks), and mixtures with sharp
+    transitions.  Results must still be bit-exact; tools/kind_probe.py tracks
+    their speed."""
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    text = np.frombuffer(synth.text(n, 9), dtype=np.uint8)
+    rnd = rng.integers(0, 256, n, dtype=np.uint8)
+    chunks = [
+        rnd,
+        np.zeros(n, dtype=np.uint8),
+        np.resize(np.frombuffer(b"abcdefg", dtype=np.uint8), n),
+        np.concatenate([text[:n // 2], rnd[:n // 2]]),
+        np.concatenate([rnd[:n // 3], text[:n // 3], np.zeros(n - 2 * (n // 3), dtype=np.uint8)]),
+        np.concatenate([text[:5000], np.zeros(100000, dtype=np.uint8), text[:n - 105000]]),
+        np.concatenate([rnd[:70000], rnd[:70000], rnd[1000:n - 139000]]),  # far repeats inside noise
+        np.concatenate([np.resize(np.frombuffer(b"xy", dtype=np.uint8), 50001), rnd[:n - 50001]]),
+    ]
+    host = np.concatenate(chunks)
+    for kw in (PARAMS_G, dict(MaxDistance=1 << 16, ChainLength=4, HashLen=5, DistanceBitCost=66)):
+        out, o, h = _run_batch(host, n, len(chunks), kw)
+        for c, chunk in enumerate(chunks):
+            ref = OracleM4(**kw).FindMatches(chunk)
+            assert same(out[o[c]:o[c + 1]], ref), f"chunk {c} params {kw}"
+            lit, cmd, dist, _, _ = histograms(chunk, ref)
+            assert (h[c, :256] == lit).all() and (h[c, 256:960] == cmd).all() and (h[c, 960:] == dist).all()
+
+
 def test_full_size_chunks_properties():
     """BASELINE config 2 shape (1 MiB chunks, params G): size-independent
     properties on every chunk + bit-exactness on a sample."""
