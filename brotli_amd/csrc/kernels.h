@@ -437,31 +437,32 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
       if (!ovf[par]) {
         consume();
       } else if (!(dbg & 4)) {
-        // Some owner got more than K1_QCAP keys.  Redo the tile one window row
-        // (1024 positions) at a time; a row that still overflows (short-period
-        // data) is redone in slices of two windows, which hold <= 128 keys in
-        // total and cannot overflow.
+        // Some owner got more than K1_QCAP keys (short-period data).  Redo the
+        // tile in spans of windows: a row of 16 windows (1024 positions) first,
+        // halving a span that still overflows, down to two windows, which hold
+        // <= 128 keys in total and cannot overflow.  ovf[2] is the flag of the
+        // current attempt; all decisions are workgroup-uniform.
         if (tid < K1_WAVES) myqn[tid] = 0;
+        if (tid == 0) ovf[2] = 0;
         lds_barrier();
+        uint32_t u = 0, span = K1_WAVES; // next window (row = u / 16, wave = u % 16), windows per attempt
 #pragma unroll 1
-        for (int k = 0; k < K1_PER; k++) {
-          produce(std::integral_constant<int, 1>{}, k, false, &ovf[2 + k]);
+        while (u < (uint32_t)(K1_PER * K1_WAVES)) {
+          const uint32_t w0 = u % K1_WAVES;
+          if (wave >= w0 && wave < w0 + span)
+            produce(std::integral_constant<int, 1>{}, (int)(u / K1_WAVES), false, &ovf[2]);
           lds_barrier();
-          if (!ovf[2 + k]) {
-            consume();
-            if (lane == 0) myqn[wave] = 0;
-            lds_barrier();
-            continue;
-          }
+          const bool over = ovf[2] != 0; // cannot happen with span == 2
+          if (!over) consume();
+          lds_barrier(); // everybody has read the flag and the queues
           if (tid < K1_WAVES) myqn[tid] = 0;
+          if (tid == 0) ovf[2] = 0;
           lds_barrier();
-#pragma unroll 1
-          for (uint32_t u = 0; u < (uint32_t)K1_WAVES; u += 2) {
-            if ((wave & ~1u) == u) produce(std::integral_constant<int, 1>{}, k, false, &ovf[2 + k]);
-            lds_barrier();
-            consume();
-            if (lane == 0) myqn[wave] = 0;
-            lds_barrier();
+          if (over && span > 2) {
+            span >>= 1;
+          } else { // (over with span == 2 cannot happen; advancing keeps the loop finite regardless)
+            u += span;
+            if (u % K1_WAVES == 0) span = K1_WAVES; // a new row starts with a full span again
           }
         }
       }
@@ -477,7 +478,6 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     // this parity's counters are next used two tiles from now
     if (lane == 0) myqn[wave] = 0;
     if (tid == 0) {
-      if (ovf[par]) ovf[2] = ovf[3] = ovf[4] = 0; // fallback flags, one per window row
       ovf[par] = 0;
     }
     if (dbg & 1) continue; // profiling aid: no chain stores
