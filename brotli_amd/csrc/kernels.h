@@ -653,12 +653,18 @@ __device__ __forceinline__ uint64_t k3_wave_of_block(uint32_t b, uint32_t nblock
 // true parse usually has that match pending from an earlier block and skips
 // the block in O(1); where it does not, k3c redoes the block with a forward
 // extension that uses the whole wave.
-constexpr int32_t K3_EXT_LIMIT = 4096;
+#ifndef M4G_K3_EXT_LIMIT
+#define M4G_K3_EXT_LIMIT 4096
+#endif
+constexpr int32_t K3_EXT_LIMIT = M4G_K3_EXT_LIMIT;
 
 // desc.out_off written by k3b, read by k3c
 constexpr uint32_t kStitchUnsynced = 0;   // whole block parsed from E[k-1], no common flush: ST + Tout hold the result
 constexpr uint32_t kStitchSynced = 1;     // joined the speculative records at keep_from
 constexpr uint32_t kStitchIncomplete = 2; // given up (entry state or this parse aborted): k3c parses the block
+// bits 8..: number of following blocks the stitch of block k went on into (k3b's chase): the status then
+// speaks about blocks k .. k+extra together, all records are in ST[k], keep_from belongs to block k+extra
+constexpr uint32_t K3_MAX_CHASE = 63;
 
 __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     const uint8_t *__restrict__ src_base, uint64_t src_total,
@@ -753,16 +759,30 @@ __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
     return;
   }
   T.error &= kStateErrRange;
-  const int32_t len = (int32_t)J.len, be = block_end(g, (int32_t)k);
-  const int32_t len_eff = (int64_t)be + K3_EXT_LIMIT < (int64_t)len ? be + K3_EXT_LIMIT : len;
-  uint32_t keep = 0;
+  const int32_t len = (int32_t)J.len;
+  uint32_t keep = 0, extra = 0; // extra: blocks after k this stitch went on into
   GlobalMem M{src, chain};
-  const bool ok = stitch_block(M, len_eff, P, g, (int32_t)k, rs + t * L.slot,
-                               min(d.n_spec, L.slot), E[t], T, sink, keep);
-  const bool gave_up = len_eff < len && (T.error & kStateTouchedEnd);
+  bool ok = false, gave_up = false;
+  for (;;) {
+    const uint32_t b = k + extra;
+    const int32_t be = block_end(g, (int32_t)b);
+    const int32_t len_eff = (int64_t)be + K3_EXT_LIMIT < (int64_t)len ? be + K3_EXT_LIMIT : len;
+    const ParseState Eb = E[t + extra];
+    const uint32_t n_spec = (Eb.error & kStateAborted) ? 0u : min(desc[t + extra].n_spec, L.slot);
+    ok = stitch_block(M, len_eff, P, g, (int32_t)b, rs + (t + extra) * L.slot, n_spec, Eb, T, sink, keep);
+    gave_up = len_eff < len && (T.error & kStateTouchedEnd);
+    // A pending match that reaches past the block end leaves nothing to compare
+    // with yet: go on into the next block (no records so far, so the slot
+    // cannot overflow) until the match ends and the parse can join a speculative
+    // one.  A block left with nothing pending, or with records, ends the stitch.
+    if (ok || gave_up || sink.n != 0 || T.m0.end == 0 || T.i < be || b + 1 >= (uint32_t)g.nblocks ||
+        extra >= K3_MAX_CHASE)
+      break;
+    extra++;
+  }
   d.n_stitch = sink.n;
-  d.keep_from = keep;
-  d.out_off = gave_up ? kStitchIncomplete : (ok ? kStitchSynced : kStitchUnsynced);
+  d.keep_from = keep; // of block k + extra
+  d.out_off = (gave_up ? kStitchIncomplete : (ok ? kStitchSynced : kStitchUnsynced)) | (extra << 8);
   desc[t] = d;
   if (!ok && !gave_up) Tout[t] = T;
   if (sink.n > L.slot) atomicOr(errors, 2u);
@@ -810,6 +830,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
   ParseState T; // the true state entering block k; meaningful only while !valid
   state_init(T, g.start, J.seed_prev);
   uint32_t err = 0;
+  uint32_t c_valid = 0, c_fast = 0, c_slow = 0, c_skip = 0; // diagnostics (M4G_TRACE)
   if (E[b0].error & kStateAborted) { // even block 0 was given up: parse from the initial state
     valid = false;
     k = 0;
@@ -819,10 +840,11 @@ __global__ __launch_bounds__(64) void k3c_validate(
   }
   while (k < K) {
     if (valid) {
+      c_valid++;
       const uint32_t kk = k + lane;
       BlockDesc d{0, 0, 0, kStitchSynced};
       if (kk < K) d = desc[b0 + kk];
-      const unsigned long long bad = __ballot(kk < K && d.out_off != kStitchSynced);
+      const unsigned long long bad = __ballot(kk < K && d.out_off != kStitchSynced); // plain sync only
       const uint32_t room = min(64u, K - k);
       const uint32_t ngood = bad ? min((uint32_t)__builtin_ctzll(bad), room) : room;
       uint32_t cnt = (uint32_t)lane < ngood ? d.n_stitch + (d.n_spec - d.keep_from) : 0;
@@ -836,21 +858,36 @@ __global__ __launch_bounds__(64) void k3c_validate(
       k += ngood;
       if (bad && k < K) {
         const int bl = (int)ngood;
-        const uint32_t status = __shfl(d.out_off, bl);
-        valid = false;
-        if (status == kStitchUnsynced) {
-          // block k did not synchronise, but it was entered in the right state:
-          // its stitch records are the true records of the whole block.
-          const uint32_t ns = __shfl(d.n_stitch, bl);
-          if (lane == bl) desc[b0 + k].out_off = off;
-          off += ns;
-          T = Tout[b0 + k];
-          k++;
-        } else {
+        const uint32_t word = __shfl(d.out_off, bl), status = word & 0xFFu, extra = word >> 8;
+        const uint32_t ns = __shfl(d.n_stitch, bl), keep = __shfl(d.keep_from, bl);
+        if (status == kStitchIncomplete) {
           // the stitch of block k was given up: redo it below from the state
           // its predecessor ended in, which is the true one (it synchronised)
+          valid = false;
           T = E[b0 + k - 1];
           T.error &= kStateErrRange;
+        } else {
+          // Block k was entered in the right state, so its stitch is true.  It
+          // covers blocks k .. k+extra: all its records sit in ST[k]; the blocks
+          // in between have none; if it synchronised, block k+extra keeps its
+          // speculative records from `keep` on.
+          const uint32_t kl = k + lane; // lane l describes block k + l
+          uint32_t tail = 0;
+          if ((uint32_t)lane <= extra && kl < K) {
+            BlockDesc nd = desc[b0 + kl];
+            const uint32_t nsp = min(nd.n_spec, L.slot);
+            nd.n_stitch = lane == 0 ? ns : 0;
+            nd.keep_from = (status == kStitchSynced && (uint32_t)lane == extra) ? keep : nsp;
+            nd.out_off = off + (lane == 0 ? 0 : ns);
+            if (status == kStitchSynced && (uint32_t)lane == extra) tail = nsp - min(keep, nsp);
+            desc[b0 + kl] = nd;
+          }
+          off += ns + __shfl(tail, (int)extra);
+          if (status == kStitchUnsynced) {
+            valid = false;
+            T = Tout[b0 + k];
+          }
+          k += extra + 1;
         }
       }
     } else {
@@ -860,6 +897,25 @@ __global__ __launch_bounds__(64) void k3c_validate(
       const ParseState Ek = E[t];
       const int32_t bb = block_begin(g, (int32_t)k), be = block_end(g, (int32_t)k);
       const uint32_t n_spec = min(d.n_spec, L.slot);
+      if (T.i >= be && k + 1 < K) {
+        // A pending match covers this block and maybe many more: they contribute
+        // no records.  All of them at once, 64 per step (never the last block,
+        // whose parse also emits the tail).
+        const uint32_t covered_end = min((uint32_t)((T.i - g.start) / g.sub_block), K - 1);
+        for (uint32_t base = k; base < covered_end; base += 64) {
+          const uint32_t kk = base + lane;
+          if (kk < covered_end) {
+            BlockDesc nd = desc[b0 + kk];
+            nd.n_stitch = 0;
+            nd.keep_from = min(nd.n_spec, L.slot);
+            nd.out_off = off;
+            desc[b0 + kk] = nd;
+          }
+        }
+        c_skip += covered_end - k;
+        k = covered_end;
+        continue;
+      }
       // Fast path.  T has nothing pending and stands at the block start, so it
       // differs from the state the speculative parse assumed only in next_emit
       // and in the repeat distance.  If no backward extension of the speculative
@@ -896,6 +952,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
           desc[t] = nd;
         }
         off += n_spec;
+        c_fast++;
         const ParseState prevT = T;
         T = Ek;
         T.error = (Ek.error & kStateErrRange) | prevT.error;
@@ -909,6 +966,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
         k++;
         continue;
       }
+      if (T.i >= be) c_skip++; else c_slow++;
       RecSink sink{st + t * L.slot, 0, L.slot};
       uint32_t keep = 0;
       WaveMem M;
@@ -932,6 +990,10 @@ __global__ __launch_bounds__(64) void k3c_validate(
   if (lane == 0) {
     counts[job] = off;
     if (err) atomicOr(errors, err);
+    atomicAdd(errors + 4, c_valid);
+    atomicAdd(errors + 5, c_fast);
+    atomicAdd(errors + 6, c_slow);
+    atomicAdd(errors + 7, c_skip);
   }
 }
 

@@ -104,11 +104,25 @@ M4G_HD bool stitch_block(const Mem &M, int32_t len, const ParseParams &P,
     T = E;
     T.error = (E.error & kStateErrRange) | err;
     keep_from = j + 1;
-  } else {
-    keep_from = n_spec;
-    if (k == g.nblocks - 1) parse_finish(len, P, T, sink);
+    return true;
   }
-  return synced;
+  keep_from = n_spec;
+  if (k == g.nblocks - 1) {
+    parse_finish(len, P, T, sink);
+    return false;
+  }
+  // No common flush, but the two parses may still have arrived in the same
+  // state at the block end (typically: both hold the same pending match).
+  // The repeat distance is dead while a match is pending -- the next flush
+  // overwrites it before any probe reads it (m4.go:113-138).  Then every
+  // speculative record of this block is dropped, the true ones are in the
+  // sink, and E is (equivalent to) the true end state.
+  const bool same_state =
+      !(E.error & kStateAborted) && T.i == E.i && T.next_emit == E.next_emit &&
+      T.m0.start == E.m0.start && T.m0.end == E.m0.end && T.m0.match == E.m0.match &&
+      T.m1.start == E.m1.start && T.m1.end == E.m1.end && T.m1.match == E.m1.match &&
+      (T.m0.end != 0 || (T.have_prev == E.have_prev && (!T.have_prev || T.prev_dist == E.prev_dist)));
+  return same_state;
 }
 
 } // namespace m4g

@@ -394,7 +394,7 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
     b->last_off.assign(chunk_off, chunk_off + nchunks + 1);
   }
 
-  HIP_TRY(hipMemsetAsync(b->d_errors, 0, 4, st));
+  HIP_TRY(hipMemsetAsync(b->d_errors, 0, 64, st));
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
   int rc = launch_find(b->p, d_src, chunk_off[nchunks], (uint32_t)b->max_chunk_bytes, b->d_chain, b->d_jobs, nullptr, njobs, b->w, b->d_counts,
                        b->d_errors, st, b->timing ? b->ev[1] : nullptr);
@@ -413,6 +413,13 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
     HIP_TRY(hipGetLastError());
   }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));
+  if (std::getenv("M4G_TRACE")) { // diagnostics of the validation pass (forces a sync)
+    uint32_t w[8] = {};
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(w, b->d_errors, sizeof(w), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[m4g] k3c: %u scan steps, %u blocks accepted by the probe check, %u parsed serially, %u skipped (covered)\n",
+                 w[4], w[5], w[6], w[7]);
+  }
   b->ran = true;
   b->last_stream = st;
   return M4G_OK;

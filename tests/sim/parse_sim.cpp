@@ -7,6 +7,8 @@
 // The chain array that kernel K1 produces on the GPU is produced here by a
 // plain sequential table sweep (m4.go:140-147).
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -83,15 +85,25 @@ int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, i
   }
   std::vector<Rec> result = RS[0];
   ParseState T = E[0];
+  int dbg_left = 6;
   int64_t synced = 0, walked = 0, nst = 0;
   for (int k = 1; k < K; k++) {
     VecSink st;
     uint32_t keep = 0;
     int32_t i0 = T.i;
+    ParseState T0 = T;
     bool ok = stitch_block(M, n, P, g, k, RS[k].data(), (uint32_t)RS[k].size(),
                            E[k], T, st, keep);
+    if (!ok && std::getenv("SIM_DEBUG") && T0.i < block_end(g, k) && dbg_left-- > 0) {
+      std::fprintf(stderr, "block %d [%d,%d) unsynced: entry i=%d m0=[%d,%d) d=%d m1=[%d,%d) ne=%d | exit i=%d m0=[%d,%d) d=%d\n", k,
+                   block_begin(g, k), block_end(g, k), T0.i, T0.m0.start, T0.m0.end, T0.m0.start - T0.m0.match,
+                   T0.m1.start, T0.m1.end, T0.next_emit, T.i, T.m0.start, T.m0.end, T.m0.start - T.m0.match);
+      for (auto &r : st.v) std::fprintf(stderr, "   true rec end=%d len=%u dist=%u flush=%d\n", rec_end(r), r.length, r.distance, (int)(r.lit_start >> 31));
+      for (auto &r : RS[k]) std::fprintf(stderr, "   spec rec end=%d len=%u dist=%u flush=%d\n", rec_end(r), r.length, r.distance, (int)(r.lit_start >> 31));
+      std::fprintf(stderr, "   spec end state i=%d m0=[%d,%d) d=%d\n", E[k].i, E[k].m0.start, E[k].m0.end, E[k].m0.start - E[k].m0.match);
+    }
     synced += ok;
-    if (ok) {
+    if (ok && !st.v.empty()) {
       int32_t e = rec_end(st.v.back());
       walked += e > i0 ? e - i0 : 0;
     } else {
