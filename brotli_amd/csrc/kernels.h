@@ -558,6 +558,7 @@ struct StagedMem {
   const uint32_t *lsrc; // LDS row of this lane: bytes [w0 - K3_BACK, w0 + K3_W + K3_FWD)
   const uint32_t *lch;  // LDS row of this lane: chain[w0 .. w0 + K3_W)
   int32_t w0;
+  int32_t give_up_at;   // > 0: a match reaching this position makes the caller drop the parse (k3a)
   __device__ __forceinline__ uint8_t ld8(int32_t p) const {
     const uint32_t o = (uint32_t)(p - w0 + K3_BACK);
     if (o < (uint32_t)K3_SRC_BYTES) return (uint8_t)(lsrc[o >> 2] >> (8 * (o & 3)));
@@ -590,6 +591,31 @@ struct StagedMem {
     return chain[p];
   }
 };
+
+// Forward extension of a speculative lane.  Same result as the generic one,
+// except that a match which has run for 256 bytes and also agrees in the 8
+// bytes just below give_up_at is reported as reaching give_up_at at once: the
+// caller abandons the block then anyway, and lanes inside long repeats stop
+// paying for extensions nobody uses.
+__device__ __forceinline__ int32_t extend_fwd(const StagedMem &M, int32_t len, int32_t i, int32_t j) {
+  int32_t run = 0;
+  while (j + 8 < len) {
+    const uint64_t a = M.ld64(i), b = M.ld64(j);
+    if (a != b) return j + (int32_t)(__builtin_ctzll(a ^ b) >> 3);
+    i += 8;
+    j += 8;
+    run += 8;
+    if (run == 256 && M.give_up_at > 0 && j + 16 < M.give_up_at) {
+      const int32_t d = M.give_up_at - 8 - j;
+      if (M.far64(i + d) == M.far64(j + d)) return M.give_up_at;
+    }
+  }
+  while (j < len && M.ld8(i) == M.ld8(j)) {
+    i++;
+    j++;
+  }
+  return j;
+}
 
 __device__ __forceinline__ int64_t shfl64(int64_t v, int srclane) {
   const uint32_t lo = __shfl((uint32_t)v, srclane), hi = __shfl((uint32_t)((uint64_t)v >> 32), srclane);
@@ -695,6 +721,7 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   M.chain = chain_base + J.chain_off;
   M.lsrc = lds_src + lane * K3_SRC_DW;
   M.lch = lds_ch + lane * K3_CH_DW;
+  M.give_up_at = len_eff < len ? len_eff : 0;
   bool aborted = false;
 
   for (int32_t e = 0; e < L.sub_block; e += K3_W) { // uniform trip count
