@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from brotli_amd import m4, synth
-C, n = 256, 1 << 20
+C, n = int(os.environ.get("KP_CHUNKS", "256")), 1 << 20
 rng = np.random.default_rng(1)
 kinds = {
     "random": rng.integers(0, 256, C * n, dtype=np.uint8),
