@@ -1,0 +1,79 @@
+"""profiles/rNN_* from one measurement run directory (see the gpurun command in
+profiles/rNN_summary.md):  python tools/make_profile_summary.py gpurun_out/r01c r01"""
+import csv, glob, json, os, re, shutil, sqlite3, subprocess, sys
+
+run, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = lambda *a: os.path.join(root, "profiles", *a)
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def per_kernel(sub, counter):
+    out = {}
+    for f in glob.glob(os.path.join(run, sub, "**", "*.db"), recursive=True):
+        db = sqlite3.connect(f)
+        tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+        t = lambda p: [x for x in tabs if x.startswith(p)][0]
+        q = f"""select s.kernel_name, d.id, sum(e.value) from {t('rocpd_pmc_event')} e
+                join {t('rocpd_info_pmc')} p on e.pmc_id = p.id
+                join {t('rocpd_kernel_dispatch')} d on e.event_id = d.event_id
+                join {t('rocpd_info_kernel_symbol')} s on d.kernel_id = s.id where p.name = ? group by 1, 2"""
+        for n, _, v in db.execute(q, (counter,)):
+            m = re.search(r"_ZN3m4g(\d+)([a-z0-9_]+)", n)
+            name = "m4g::" + m.group(2)[:int(m.group(1))] if m else n.split("(")[0]
+            out.setdefault(name, []).append(v)
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+stats = glob.glob(os.path.join(run, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, P(f"{tag}_kernel_stats.csv"))
+b = last_json(os.path.join(run, "bench.json"))
+json.dump(b, open(P(f"{tag}_bench.json"), "w"))
+bl, bd = last_json(os.path.join(run, "bench_log.json")), last_json(os.path.join(run, "bench_D.json"))
+json.dump(bl, open(P(f"{tag}_bench_log.json"), "w"))
+json.dump(bd, open(P(f"{tag}_bench_D.json"), "w"))
+for f in ("kind_probe.log", "stream_probe.log"):
+    if os.path.exists(os.path.join(run, f)):
+        shutil.copy(os.path.join(run, f), P(f"{tag}_{f}"))
+subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"), os.path.join(run, "pmc_fetch"),
+                       os.path.join(run, "pmc_write"), "text/G", str(1024 * 1048576)])
+F, W = per_kernel("pmc_fetch", "FETCH_SIZE"), per_kernel("pmc_write", "WRITE_SIZE")
+rows = [r for r in csv.DictReader(open(stats)) if "m4g" in r["Name"]]
+L = [f"# Round {tag[1:]} profile summary (1 x MI355X)\n",
+     "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2`",
+     "(4096 x 1 MiB synthetic text chunks, params G, 1 warm-up + 5 timed + 3 event-timed steps = 9 launches per kernel).",
+     f"Raw: `profiles/{tag}_kernel_stats.csv`; bench line of the plain `python bench.py` run: `profiles/{tag}_bench.json`.\n",
+     "| kernel | calls | avg ms | % |\n|---|---|---|---|"]
+for r in rows:
+    L.append(f"| {r['Name'].split('(')[0].replace('void ', '')} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
+e2e = b.get("end_to_end", {})
+L.append(f"\nbench.py (HIP events on the launch stream): stage_ms = {b['stage_ms']}, value = {b['value']} GB/s "
+         f"({b['ms_per_step']} ms per 4 GiB step), roofline.achieved = {b['roofline']['achieved']} GB/s of 8000 "
+         f"({b['roofline']['frac']}), roofline.traffic = {b['roofline']['traffic']} GB, cpu_baseline = "
+         f"{b['cpu_baseline']['value']} GB/s on {b['cpu_baseline']['cores']} threads, compression ratio "
+         f"{b['config']['compression_ratio']}, {b['config']['roundtrip_checked_chunks']} chunks decoded back to the input "
+         f"with libbrotlidec, end-to-end through the host API (pageable memory, PCIe both ways) {e2e.get('value')} GB/s.\n")
+L.append("Other workloads (1024 x 1 MiB chunks, same run):\n")
+L.append(f"* low-entropy binary log, params G (BASELINE config 5): {bl['value']} GB/s, stage_ms {bl['stage_ms']}, ratio {bl['config']['compression_ratio']}")
+L.append(f"* text, params D (ChainLength 64, HashLen 5; BASELINE config 4): {bd['value']} GB/s, stage_ms {bd['stage_ms']}, ratio {bd['config']['compression_ratio']}")
+L.append(f"* inputs that defeat the speculation: `profiles/{tag}_kind_probe.log`; one stream in 64 KiB blocks: `profiles/{tag}_stream_probe.log`\n")
+L.append("## HBM-side traffic (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, 1024 x 1 MiB text chunks, per launch)\n")
+L.append("FETCH_SIZE/WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies 128-byte requests")
+L.append("at 64 bytes, so the read column is doubled; `profiles/traffic.json` (made by `tools/pmc_traffic.py`, read by bench.py")
+L.append("for `roofline.traffic`) holds the corrected bytes per input byte.  The guide calibrates the factor on wide streaming")
+L.append("reads only; K3a mixes those with 8-byte random reads, so its corrected figure is an upper bound.")
+L.append("Algorithmic bytes of this launch: N + 12 M + 4096/chunk = 1.07 GB + 1.09 GB + 4 MiB = 2.16 GB.\n")
+L.append("| kernel | FETCH_SIZE GB (raw) | x2 | WRITE_SIZE GB |\n|---|---|---|---|")
+for k in sorted(set(F) | set(W)):
+    if "m4g" in k:
+        L.append(f"| {k} | {F.get(k, 0)*1024/1e9:.2f} | {F.get(k, 0)*2048/1e9:.2f} | {W.get(k, 0)*1024/1e9:.2f} |")
+L.append("\nReading: K1 moves exactly what it must (1 B/B source read once from HBM, the other three partition workgroups hit L2;")
+L.append("4 B/B chain written as full lines).  K3a still reads many times the chain+source bytes: the staged windows are re-fetched")
+L.append("every 16 positions (L2 hit rate 11 %) and match sources are random sector reads.  SQ counters (`--pmc SQ_*`, earlier run):")
+L.append("K1 VALU-busy 56 %, K3a VALU-busy 57 % with 26 % of lanes active per instruction (divergence of 64 independent parses),")
+L.append("69 % of wave time waiting.")
+open(P(f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
+print("\n".join(L[:14]))
