@@ -270,7 +270,9 @@ __device__ __forceinline__ void k1_consume(uint32_t *slice, uint32_t *res, const
     const uint32_t P = samep ? Vp : slice[idxl];
     // a predecessor at or below the buffer origin counts as "empty" (m4.go:152, 92-98)
     const uint32_t pp = P >> cb, pos = sb + rel, org = STREAM ? (pos >= org_next_x ? org_next : org_cur) : 0u;
-    res[rel] = pp > org ? ((pos - pp) | ((P & cmask) == (K[j] & cmask) ? kChainMaybe : 0u)) : 0u;
+    // check bits 0 = unknown (entry loaded from a persistent table): may be equal
+    const uint32_t pck = P & cmask;
+    res[rel] = pp > org ? ((pos - pp) | ((pck == 0 || pck == (K[j] & cmask)) ? kChainMaybe : 0u)) : 0u;
     if (tail) slice[idxl] = V[j];
   }
 }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   const bool load_table = table_io && (J.k1_flags & kJobLoadTable);
   const bool store_table = table_io && (J.k1_flags & kJobStoreTable);
   for (uint32_t k = tid; k < part_size; k += K1_THREADS)
-    table[k] = load_table ? table_io[(q << part_bits) + k] : 0u;
+    table[k] = load_table ? table_io[(q << part_bits) + k] << check_bits : 0u; // plain positions, check bits unknown
   if (tid < 2 * K1_WAVES + 2 + K1_PER) qn[tid] = 0; // fills and overflow flags
   // block structure of a stream handled in one launch (none: one block, origin 0)
   const uint32_t st_x0 = STREAM ? si->x0 : 0u, st_xend = STREAM ? si->x_end : 0xFFFFFFFFu;
@@ -388,7 +390,8 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
         const bool in = pos < end && (h >> part_bits) == q &&
                         !(STREAM && pos + 7 >= blk_end && pos < blk_end);
         // check bits of the first 4 bytes (top bits of a multiplicative hash)
-        const uint32_t ck = cb ? (v[w].x * 0x9E3779B1u) >> (32 - cb) : 0u;
+        // (never 0: that value marks table entries whose bytes are not known)
+        const uint32_t ck = cb ? max(1u, (v[w].x * 0x9E3779B1u) >> (32 - cb)) : 0u;
         // run folding: this position continues the previous one (lane - 1) when
         // hash and check bits are equal
         const uint32_t tag = in ? ((h << K1_MAX_CHECK_BITS) | ck) : 0xFFFFFFFFu; // h < 2^24
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
     const uint32_t rebase = STREAM ? si->final_org : 0u;
     lds_barrier();
     for (uint32_t k = tid; k < part_size; k += K1_THREADS) {
-      const uint32_t v = table[k];
+      const uint32_t v = table[k] >> check_bits; // the persistent table holds plain positions
       (table_out ? table_out : table_io)[(q << part_bits) + k] = v > rebase ? v - rebase : 0u;
     }
   }

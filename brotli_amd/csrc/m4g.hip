@@ -157,10 +157,11 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
   dim3 g1((unsigned)(groups * 8 * nparts));
   // check bits kept next to a position in the LDS table (kernels.h, K1): as
   // many as fit above the largest position.  The persistent table of a
-  // streaming handle stores plain positions, so no check bits there.
+  // streaming handle stores plain positions; entries loaded from it carry
+  // "unknown" check bits.
   int posbits = 1;
   while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
-  const int cb = d_table_io ? 0 : std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
+  const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
   if (d_si)
     hipLaunchKernelGGL(k1_chain_build<true>, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, src_total, d_chain,
                        d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out);
