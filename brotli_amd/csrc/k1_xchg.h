@@ -1,0 +1,261 @@
+// k1_xchg.h -- K1 (chain build) with an ordered LDS exchange instead of a sort.
+// Included by kernels.h after the K1 helpers.
+//
+// chain[i] = i - table[h(i)], table[h(i)] = i  (m4.go:140-147) for every
+// inserted position in order is one atomic exchange per position, provided the
+// exchanges on one table entry happen in position order.  Two hardware facts
+// give that order without sorting anything:
+//   * the lanes of ONE ds_wrxchg_rtn_b32 instruction that hit the same LDS
+//     address are performed in ascending lane order
+//     (tools/probes/lds_xchg_order.hip: 134 M exchanges, 78 M of them behind an
+//     earlier lane of the same instruction, 0 deviations; libm4g repeats a short
+//     form of the probe when a context or plan is created and falls back to the
+//     sorting kernel if it ever fails);
+//   * the LDS instructions of one wave are performed in program order.
+// So the keys of a tile only have to reach ONE wave in position order:
+//   * 15 PRODUCER waves hash the tile (wave w: positions [192 w, 192 w + 192) in
+//     three rows of 64), keep the ~1/nparts of them that belong to this
+//     workgroup's table partition and compact them, in position order, into a
+//     dense key queue (ballot + mbcnt inside a wave, a 15-entry prefix sum of the
+//     wave counts across waves);
+//   * the CONSUMER wave (wave 15) walks the queue of the PREVIOUS tile 64 keys
+//     per exchange instruction and overwrites each key with its chain entry;
+//   * two tiles later the producers pick their chain entries up from the queue
+//     slots they remember and store them, 64 consecutive positions per wave
+//     instruction.
+// Any multiplicity of a hash inside a tile (zero pages, short periods, log
+// records) is handled by the LDS atomic unit itself: no run folding, no queue
+// overflow, no fallback path.  Two LDS-only barriers per tile.
+#pragma once
+
+namespace m4g {
+
+constexpr int KX_THREADS = 1024;
+constexpr int KX_PROD_WAVES = 15;                       // wave 15 consumes
+constexpr int KX_PER = 3;                               // rows of 64 positions per producer wave and tile
+constexpr int KX_WAVE_SPAN = 64 * KX_PER;               // consecutive positions of one producer wave
+constexpr int KX_SUB = KX_PROD_WAVES * KX_WAVE_SPAN;    // positions per tile (2880)
+constexpr int KX_GROUPS = KX_SUB / 16 + 2;              // 16-byte groups staged per tile (+halo)
+constexpr int KX_TILE_BYTES = KX_GROUPS * 16;
+// key = index within the partition << 17 | position in tile << 5 | check bits
+constexpr int KX_KEY_IDX_SHIFT = 17;
+constexpr int KX_KEY_REL_SHIFT = 5;
+constexpr uint32_t KX_KEY_REL_MASK = 0xFFFu;
+static_assert(KX_SUB <= 4096, "tile position must fit the key");
+static_assert(K1_MAX_CHECK_BITS <= KX_KEY_REL_SHIFT, "check bits must fit the key");
+static_assert(KX_GROUPS <= KX_THREADS, "one 16-byte group per thread");
+
+// dynamic LDS of k1x_chain_build: table | tile image | 2 key queues | 2 x 16 wave counts
+constexpr size_t k1x_lds_bytes(int part_bits) {
+  return ((size_t)1 << part_bits) * 4 + (size_t)KX_TILE_BYTES + 2 * (size_t)KX_SUB * 4 + 2 * 16 * 4;
+}
+
+template <bool STREAM>
+__global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
+    const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
+    const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
+    int hash_len, int table_bits, int part_bits, int check_bits, int dbg,
+    const StreamInfo *__restrict__ si, uint32_t *__restrict__ table_out) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t part_size = 1u << part_bits;
+  uint32_t *table = lds;
+  uint32_t *img = lds + part_size;               // KX_TILE_BYTES / 4 dwords
+  uint32_t *buf = img + KX_TILE_BYTES / 4;       // 2 x KX_SUB keys / chain entries, by tile parity
+  uint32_t *cnt = buf + 2 * KX_SUB;              // 2 x 16 keys per producer wave, by tile parity
+
+  const int nparts = 1 << (table_bits - part_bits);
+  // XCD-aware placement: blocks b and b+8 share an XCD, so give the nparts
+  // partitions of one job the same b % 8 (they read the same input bytes).
+  const uint32_t b = blockIdx.x;
+  const uint32_t x = b & 7, r = b >> 3;
+  const uint32_t q = r % nparts;
+  const uint32_t job = (r / nparts) * 8 + x;
+  if (job >= (uint32_t)njobs) return;
+
+  const Job J = jobs[job];
+  uint32_t *chain = chain_base + J.chain_off;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const bool consumer = wave == (uint32_t)KX_PROD_WAVES;
+  if (consumer) __builtin_amdgcn_s_setprio(3); // the one wave everybody waits for
+
+  const bool load_table = table_io && (J.k1_flags & kJobLoadTable);
+  const bool store_table = table_io && (J.k1_flags & kJobStoreTable);
+  for (uint32_t k = tid; k < part_size; k += KX_THREADS)
+    table[k] = load_table ? table_io[(q << part_bits) + k] << check_bits : 0u; // plain positions, check bits unknown
+  const uint32_t st_x0 = STREAM ? si->x0 : 0u, st_xend = STREAM ? si->x_end : 0xFFFFFFFFu;
+  const uint32_t st_block = STREAM ? si->block_size : 0u, st_nbp = STREAM ? si->nbp : 1u;
+  uint32_t bpi = 0; // breakpoint in force at the current tile
+  const uint32_t store_from = STREAM ? J.store_from : 0u;
+
+  // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces
+  const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
+  const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
+  const uint32_t mul_lo = (uint32_t)kHashMul64, mul_hi = (uint32_t)(kHashMul64 >> 32);
+  const uint32_t shift = 32 - table_bits;
+  const uint32_t idx_mask = part_size - 1;
+  const uint32_t cb = (uint32_t)check_bits; // <= K1_MAX_CHECK_BITS and positions << cb fit 32 bits
+  const uint32_t cmask = (1u << cb) - 1;
+  const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
+  const uint32_t ntiles = J.start < end ? (end - J.start + KX_SUB - 1) / KX_SUB : 0;
+
+  auto tile_origin = [&](uint32_t base) -> int64_t {
+    return (int64_t)((J.src_off + base) & ~(uint64_t)15);
+  };
+  uint4 pre = make_uint4(0, 0, 0, 0);
+  if (ntiles > 0 && tid < KX_GROUPS) {
+    pre = load_group(src_base, tile_origin(J.start) + 16 * (int64_t)tid, (int64_t)src_total);
+    reinterpret_cast<uint4 *>(img)[tid] = pre;
+    if (ntiles > 1)
+      pre = load_group(src_base, tile_origin(J.start + KX_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
+  }
+  lds_barrier(); // table and the first tile image are in place
+
+  // queue slots of this lane's positions in the two previous tiles
+  uint32_t slot1[KX_PER], slot2[KX_PER], in1 = 0, in2 = 0;
+#pragma unroll
+  for (int j = 0; j < KX_PER; j++) slot1[j] = slot2[j] = 0;
+  // origin in force at the tile start and the next change (at most one per
+  // tile: slides are more than MaxDistance >= KX_SUB positions apart); p_*: of
+  // the previous tile, which is the one the consumer works on
+  uint32_t org_cur = 0, org_next_x = 0xFFFFFFFFu, org_next = 0;
+  uint32_t p_org_cur = 0, p_org_next_x = 0xFFFFFFFFu, p_org_next = 0;
+
+#pragma unroll 1
+  for (uint32_t t = 0; t < ntiles + 2; t++) {
+    const uint32_t sb = J.start + t * KX_SUB; // (may run past `end` in the two drain iterations)
+    const uint32_t par = t & 1;
+    uint32_t *bufc = buf + par * KX_SUB; // holds the chain entries of tile t-2, then receives the keys of tile t
+    uint32_t blk_end = 0xFFFFFFFFu;      // end of the block the tile starts in: its last 7 positions are not inserted
+    if (STREAM) {
+      p_org_cur = org_cur, p_org_next_x = org_next_x, p_org_next = org_next;
+      while (bpi + 1 < st_nbp && si->bp_x[bpi + 1] <= sb) bpi++;
+      org_cur = si->bp_org[bpi];
+      org_next_x = 0xFFFFFFFFu;
+      if (bpi + 1 < st_nbp) {
+        org_next_x = si->bp_x[bpi + 1];
+        org_next = si->bp_org[bpi + 1];
+      }
+      if (sb >= st_x0) blk_end = min(st_xend, st_x0 + ((sb - st_x0) / st_block + 1) * st_block);
+      else blk_end = st_x0; // history of earlier calls is never re-inserted (segments start at x0)
+    }
+
+    uint32_t key[KX_PER], in0 = 0;
+    unsigned long long bal[KX_PER];
+    if (!consumer) {
+      // chain entries of tile t-2 (the consumer finished it one iteration ago)
+      if (t >= 2 && !(dbg & 1)) {
+        const uint32_t p0 = sb - 2 * KX_SUB + wave * KX_WAVE_SPAN + lane;
+#pragma unroll
+        for (int j = 0; j < KX_PER; j++)
+          if ((in2 >> j & 1) && p0 + j * 64 >= store_from) chain[p0 + j * 64] = bufc[slot2[j]];
+      }
+      // hash tile t
+      uint32_t total = 0;
+      if (t < ntiles && !(dbg & 4)) {
+        const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
+        uint2 v[KX_PER];
+#pragma unroll
+        for (int j = 0; j < KX_PER; j++) v[j] = lds_ld64(img, lds_off0 + wave * KX_WAVE_SPAN + j * 64 + lane);
+#pragma unroll
+        for (int j = 0; j < KX_PER; j++) {
+          const uint32_t rel = wave * KX_WAVE_SPAN + j * 64 + lane;
+          const uint32_t lo = v[j].x & mask_lo, hi = v[j].y & mask_hi;
+          const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
+          const uint32_t pos = sb + rel;
+          const bool in = pos < end && (h >> part_bits) == q &&
+                          !(STREAM && pos + 7 >= blk_end && pos < blk_end);
+          // check bits of the first 4 bytes (never 0: that value marks table
+          // entries whose bytes are not known)
+          const uint32_t ck = cb ? max(1u, (v[j].x * 0x9E3779B1u) >> (32 - cb)) : 0u;
+          key[j] = ((h & idx_mask) << KX_KEY_IDX_SHIFT) | (rel << KX_KEY_REL_SHIFT) | ck;
+          bal[j] = __ballot(in);
+          if (in) in0 |= 1u << j;
+          total += (uint32_t)__builtin_popcountll(bal[j]);
+        }
+      }
+      if (lane == 0) cnt[par * 16 + wave] = total;
+    } else if (t >= 1 && t - 1 < ntiles && !(dbg & 2)) {
+      // CONSUME tile t-1: one exchange per key, in queue (= position) order
+      uint32_t *bufp = buf + (par ^ 1) * KX_SUB;
+      uint32_t n = lane < (uint32_t)KX_PROD_WAVES ? cnt[(par ^ 1) * 16 + lane] : 0u;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) n += __shfl_xor(n, o);
+      n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+      const uint32_t sbp = sb - KX_SUB;
+      constexpr int U = 4; // batches in flight
+#pragma unroll 1
+      for (uint32_t e0 = 0; e0 < n; e0 += 64 * U) {
+        uint32_t k[U], old[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t e = e0 + u * 64 + lane;
+          k[u] = e < n ? bufp[e] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t e = e0 + u * 64 + lane;
+          const uint32_t pos = sbp + ((k[u] >> KX_KEY_REL_SHIFT) & KX_KEY_REL_MASK);
+          old[u] = 0;
+          if (e < n)
+            old[u] = __hip_atomic_exchange(&table[k[u] >> KX_KEY_IDX_SHIFT], (pos << cb) | (k[u] & cmask),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t e = e0 + u * 64 + lane;
+          const uint32_t pos = sbp + ((k[u] >> KX_KEY_REL_SHIFT) & KX_KEY_REL_MASK);
+          // a predecessor at or below the buffer origin counts as "empty" (m4.go:152, 92-98)
+          const uint32_t pp = old[u] >> cb, pck = old[u] & cmask;
+          const uint32_t org = STREAM ? (pos >= p_org_next_x ? p_org_next : p_org_cur) : 0u;
+          // check bits 0 = unknown (entry loaded from a persistent table): may be equal
+          const uint32_t res = pp > org ? ((pos - pp) | ((pck == 0 || pck == (k[u] & cmask)) ? kChainMaybe : 0u)) : 0u;
+          if (e < n) bufp[e] = res;
+        }
+      }
+    }
+    lds_barrier(); // wave counts of tile t complete; everybody is done with the tile image and with bufc
+    if (!consumer && t < ntiles) {
+      // ordered compaction: queue slot = keys of earlier waves + of earlier rows + of earlier lanes
+      uint32_t c = lane < (uint32_t)KX_PROD_WAVES ? cnt[par * 16 + lane] : 0u;
+      uint32_t incl = c;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += up;
+      }
+      uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(incl - c), (int)wave);
+#pragma unroll
+      for (int j = 0; j < KX_PER; j++) {
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[j] >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bal[j], 0u));
+        slot2[j] = slot1[j];
+        slot1[j] = base + below;
+        if (in0 >> j & 1) bufc[slot1[j]] = key[j];
+        base += (uint32_t)__builtin_popcountll(bal[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KX_PER; j++) slot2[j] = slot1[j];
+    }
+    in2 = in1;
+    in1 = in0;
+    // stage the next tile image and start fetching the one after it
+    if (tid < KX_GROUPS && t + 1 < ntiles) {
+      reinterpret_cast<uint4 *>(img)[tid] = pre;
+      if (t + 2 < ntiles)
+        pre = load_group(src_base, tile_origin(sb + 2 * KX_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
+    }
+    lds_barrier(); // keys of tile t queued, next image staged
+  }
+
+  if (store_table) { // entries relative to the origin after the call, at or below it = empty
+    const uint32_t rebase = STREAM ? si->final_org : 0u;
+    for (uint32_t k = tid; k < part_size; k += KX_THREADS) {
+      const uint32_t v = table[k] >> check_bits; // the persistent table holds plain positions
+      (table_out ? table_out : table_io)[(q << part_bits) + k] = v > rebase ? v - rebase : 0u;
+    }
+  }
+}
+
+} // namespace m4g

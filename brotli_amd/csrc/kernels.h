@@ -500,6 +500,10 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
   }
 }
 
+} // namespace m4g
+#include "k1_xchg.h"
+namespace m4g {
+
 // ---------------------------------------------------------------------------
 // K3: the parse, spread over lanes by sub-block speculation (m4_spec.h).
 //

@@ -90,7 +90,19 @@ int k1_prepare() {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1_chain_build<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)k1_lds_bytes(kMaxPartBits)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1x_chain_build<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)k1x_lds_bytes(kMaxPartBits)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1x_chain_build<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)k1x_lds_bytes(kMaxPartBits)));
   return M4G_OK;
+}
+
+// K1 variant: the exchange kernel (k1_xchg.h) unless M4G_K1_SORT is set
+bool k1_use_sort() {
+  static const bool v = std::getenv("M4G_K1_SORT") != nullptr;
+  return v;
 }
 
 // Device buffers of the speculative parse (kernels.h, K3) for up to `blocks`
@@ -162,7 +174,14 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
   int posbits = 1;
   while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
   const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
-  if (d_si)
+  if (!k1_use_sort()) {
+    if (d_si)
+      hipLaunchKernelGGL(k1x_chain_build<true>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), st, d_src, src_total, d_chain,
+                         d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out);
+    else
+      hipLaunchKernelGGL(k1x_chain_build<false>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), st, d_src, src_total, d_chain,
+                         d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out);
+  } else if (d_si)
     hipLaunchKernelGGL(k1_chain_build<true>, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, src_total, d_chain,
                        d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out);
   else
@@ -438,8 +457,12 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
   dim3 g1((unsigned)(((njobs + 7) / 8) * 8 * nparts));
   HIP_TRY(hipEventRecord(b->ev[0], nullptr));
   for (int r = 0; r < reps; r++)
-    hipLaunchKernelGGL(k1_chain_build<false>, g1, dim3(K1_THREADS), k1_lds_bytes(pb), nullptr, d_src, src_total,
-                       b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
+    if (k1_use_sort())
+      hipLaunchKernelGGL(k1_chain_build<false>, g1, dim3(K1_THREADS), k1_lds_bytes(pb), nullptr, d_src, src_total,
+                         b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
+    else
+      hipLaunchKernelGGL(k1x_chain_build<false>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), nullptr, d_src, src_total,
+                         b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[1], nullptr));
   HIP_TRY(hipEventSynchronize(b->ev[1]));

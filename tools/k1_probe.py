@@ -14,7 +14,7 @@ off = np.arange(C + 1, dtype=np.uint64) * n
 d_out = torch.empty(3 * (n // 6) * C, dtype=torch.int32, device=dev); d_off = torch.empty(C + 1, dtype=torch.int64, device=dev)
 plan.run(d_src, off, d_out, d_off, None); torch.cuda.synchronize()
 L = m4.lib(); L.m4g_debug_k1_only.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
-for dbg in (0, 1, 4, 2):
+for dbg in [int(x) for x in (sys.argv[3].split(',') if len(sys.argv) > 3 else '0,1,4,2'.split(','))]:
     ms = ctypes.c_float()
     rc = L.m4g_debug_k1_only(plan._h, d_src.data_ptr(), n * C, C, dbg, 3, ctypes.byref(ms))
     print(f"{kind} chunks {C} dbg {dbg}: rc {rc} {ms.value:.3f} ms  ({n*C/ms.value/1e6:.1f} GB/s)")
