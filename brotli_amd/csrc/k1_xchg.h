@@ -13,42 +13,47 @@
 //     sorting kernel if it ever fails);
 //   * the LDS instructions of one wave are performed in program order.
 // So the keys of a tile only have to reach ONE wave in position order:
-//   * 15 PRODUCER waves hash the tile (wave w: positions [192 w, 192 w + 192) in
-//     three rows of 64), keep the ~1/nparts of them that belong to this
-//     workgroup's table partition and compact them, in position order, into a
-//     dense key queue (ballot + mbcnt inside a wave, a 15-entry prefix sum of the
-//     wave counts across waves);
-//   * the CONSUMER wave (wave 15) walks the queue of the PREVIOUS tile 64 keys
-//     per exchange instruction and overwrites each key with its chain entry;
-//   * two tiles later the producers pick their chain entries up from the queue
-//     slots they remember and store them, 64 consecutive positions per wave
-//     instruction.
+//   * 15 PRODUCER waves hash the tile.  Wave w owns KX_WAVE_SPAN consecutive
+//     positions (rows of 64) and reads their 8-byte windows straight from
+//     global memory (unaligned 8-byte loads, one tile ahead).  It keeps the
+//     ~1/nparts of its positions that belong to this workgroup's table
+//     partition and compacts their keys, in position order (ballot + mbcnt),
+//     into ITS segment of the tile's key queue;
+//   * the CONSUMER wave (wave 15) walks the segments of the PREVIOUS tile in
+//     wave order, 64 keys per exchange instruction, and overwrites each key
+//     with its chain entry;
+//   * two tiles later every producer picks its chain entries up from its own
+//     segment and stores them, 64 consecutive positions per wave instruction.
+// A segment is written and read back by one wave only, so the single LDS-only
+// barrier per tile is the hand-over between producers and consumer.
 // Any multiplicity of a hash inside a tile (zero pages, short periods, log
 // records) is handled by the LDS atomic unit itself: no run folding, no queue
-// overflow, no fallback path.  Two LDS-only barriers per tile.
+// overflow, no fallback path.
 #pragma once
 
 namespace m4g {
 
 constexpr int KX_THREADS = 1024;
 constexpr int KX_PROD_WAVES = 15;                       // wave 15 consumes
-constexpr int KX_PER = 3;                               // rows of 64 positions per producer wave and tile
+#ifndef M4G_KX_PER
+#define M4G_KX_PER 4
+#endif
+constexpr int KX_PER = M4G_KX_PER;                      // rows of 64 positions per producer wave and tile
 constexpr int KX_WAVE_SPAN = 64 * KX_PER;               // consecutive positions of one producer wave
-constexpr int KX_SUB = KX_PROD_WAVES * KX_WAVE_SPAN;    // positions per tile (2880)
-constexpr int KX_GROUPS = KX_SUB / 16 + 2;              // 16-byte groups staged per tile (+halo)
-constexpr int KX_TILE_BYTES = KX_GROUPS * 16;
-// key = index within the partition << 17 | position in tile << 5 | check bits
+constexpr int KX_SUB = KX_PROD_WAVES * KX_WAVE_SPAN;    // positions per tile (3840)
+// key = index within the partition << 17 | position in tile << cb | check bits (cb of them)
 constexpr int KX_KEY_IDX_SHIFT = 17;
 constexpr int KX_KEY_REL_SHIFT = 5;
 constexpr uint32_t KX_KEY_REL_MASK = 0xFFFu;
 static_assert(KX_SUB <= 4096, "tile position must fit the key");
 static_assert(K1_MAX_CHECK_BITS <= KX_KEY_REL_SHIFT, "check bits must fit the key");
-static_assert(KX_GROUPS <= KX_THREADS, "one 16-byte group per thread");
+constexpr int KX_U = 5; // exchange instructions the consumer keeps in flight
 
-// dynamic LDS of k1x_chain_build: table | tile image | 2 key queues | 2 x 16 wave counts
+// dynamic LDS of k1x_chain_build: table | 2 key queues | 2 x 16 wave counts
 constexpr size_t k1x_lds_bytes(int part_bits) {
-  return ((size_t)1 << part_bits) * 4 + (size_t)KX_TILE_BYTES + 2 * (size_t)KX_SUB * 4 + 2 * 16 * 4;
+  return ((size_t)1 << part_bits) * 4 + 2 * (size_t)KX_SUB * 4 + 2 * 16 * 4;
 }
+static_assert(k1x_lds_bytes(15) <= 160 * 1024, "LDS of one CU");
 
 template <bool STREAM>
 __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
@@ -59,8 +64,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
   extern __shared__ uint32_t lds[];
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
-  uint32_t *img = lds + part_size;               // KX_TILE_BYTES / 4 dwords
-  uint32_t *buf = img + KX_TILE_BYTES / 4;       // 2 x KX_SUB keys / chain entries, by tile parity
+  uint32_t *buf = lds + part_size;               // 2 x KX_SUB keys / chain entries, by tile parity
   uint32_t *cnt = buf + 2 * KX_SUB;              // 2 x 16 keys per producer wave, by tile parity
 
   const int nparts = 1 << (table_bits - part_bits);
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
   const bool store_table = table_io && (J.k1_flags & kJobStoreTable);
   for (uint32_t k = tid; k < part_size; k += KX_THREADS)
     table[k] = load_table ? table_io[(q << part_bits) + k] << check_bits : 0u; // plain positions, check bits unknown
+  if (tid < 32) cnt[tid] = 0;
   const uint32_t st_x0 = STREAM ? si->x0 : 0u, st_xend = STREAM ? si->x_end : 0xFFFFFFFFu;
   const uint32_t st_block = STREAM ? si->block_size : 0u, st_nbp = STREAM ? si->nbp : 1u;
   uint32_t bpi = 0; // breakpoint in force at the current tile
@@ -99,19 +104,24 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
   const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
   const uint32_t ntiles = J.start < end ? (end - J.start + KX_SUB - 1) / KX_SUB : 0;
 
-  auto tile_origin = [&](uint32_t base) -> int64_t {
-    return (int64_t)((J.src_off + base) & ~(uint64_t)15);
+  // the 8 bytes at this lane's KX_PER positions of the tile at `base`
+  // (positions past the buffer read its last 8 bytes; they are never used)
+  const uint32_t my_rel = wave * KX_WAVE_SPAN + lane; // row 0
+  auto load_windows = [&](uint32_t base, uint2 *v) {
+#pragma unroll
+    for (int j = 0; j < KX_PER; j++) {
+      uint64_t a = J.src_off + base + my_rel + j * 64;
+      if (a + 8 > src_total) a = src_total - 8;
+      __builtin_memcpy(&v[j], src_base + a, 8);
+    }
   };
-  uint4 pre = make_uint4(0, 0, 0, 0);
-  if (ntiles > 0 && tid < KX_GROUPS) {
-    pre = load_group(src_base, tile_origin(J.start) + 16 * (int64_t)tid, (int64_t)src_total);
-    reinterpret_cast<uint4 *>(img)[tid] = pre;
-    if (ntiles > 1)
-      pre = load_group(src_base, tile_origin(J.start + KX_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
-  }
-  lds_barrier(); // table and the first tile image are in place
+  uint2 vn[KX_PER]; // windows of the next tile
+#pragma unroll
+  for (int j = 0; j < KX_PER; j++) vn[j] = make_uint2(0, 0);
+  if (!consumer && ntiles > 0) load_windows(J.start, vn);
+  lds_barrier(); // table in place
 
-  // queue slots of this lane's positions in the two previous tiles
+  // where this lane's keys went in the two previous tiles (queue slots, rows as bits)
   uint32_t slot1[KX_PER], slot2[KX_PER], in1 = 0, in2 = 0;
 #pragma unroll
   for (int j = 0; j < KX_PER; j++) slot1[j] = slot2[j] = 0;
@@ -143,9 +153,13 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
     uint32_t key[KX_PER], in0 = 0;
     unsigned long long bal[KX_PER];
     if (!consumer) {
+      uint2 v[KX_PER];
+#pragma unroll
+      for (int j = 0; j < KX_PER; j++) v[j] = vn[j];
+      if (t + 1 < ntiles) load_windows(sb + KX_SUB, vn);
       // chain entries of tile t-2 (the consumer finished it one iteration ago)
       if (t >= 2 && !(dbg & 1)) {
-        const uint32_t p0 = sb - 2 * KX_SUB + wave * KX_WAVE_SPAN + lane;
+        const uint32_t p0 = sb - 2 * KX_SUB + my_rel;
 #pragma unroll
         for (int j = 0; j < KX_PER; j++)
           if ((in2 >> j & 1) && p0 + j * 64 >= store_from) chain[p0 + j * 64] = bufc[slot2[j]];
@@ -153,13 +167,9 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
       // hash tile t
       uint32_t total = 0;
       if (t < ntiles && !(dbg & 4)) {
-        const uint32_t lds_off0 = (uint32_t)((J.src_off + sb) & 15);
-        uint2 v[KX_PER];
-#pragma unroll
-        for (int j = 0; j < KX_PER; j++) v[j] = lds_ld64(img, lds_off0 + wave * KX_WAVE_SPAN + j * 64 + lane);
 #pragma unroll
         for (int j = 0; j < KX_PER; j++) {
-          const uint32_t rel = wave * KX_WAVE_SPAN + j * 64 + lane;
+          const uint32_t rel = my_rel + j * 64;
           const uint32_t lo = v[j].x & mask_lo, hi = v[j].y & mask_hi;
           const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
           const uint32_t pos = sb + rel;
@@ -168,7 +178,8 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
           // check bits of the first 4 bytes (never 0: that value marks table
           // entries whose bytes are not known)
           const uint32_t ck = cb ? max(1u, (v[j].x * 0x9E3779B1u) >> (32 - cb)) : 0u;
-          key[j] = ((h & idx_mask) << KX_KEY_IDX_SHIFT) | (rel << KX_KEY_REL_SHIFT) | ck;
+          // the low 17 key bits + (tile start << cb) are the table value of the position
+          key[j] = ((h & idx_mask) << KX_KEY_IDX_SHIFT) | (rel << cb) | ck;
           bal[j] = __ballot(in);
           if (in) in0 |= 1u << j;
           total += (uint32_t)__builtin_popcountll(bal[j]);
@@ -176,45 +187,51 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
       }
       if (lane == 0) cnt[par * 16 + wave] = total;
     } else if (t >= 1 && t - 1 < ntiles && !(dbg & 2)) {
-      // CONSUME tile t-1: one exchange per key, in queue (= position) order
-      uint32_t *bufp = buf + (par ^ 1) * KX_SUB;
+      // CONSUME tile t-1: one exchange per key, in queue (= position) order.
+      // This wave's instruction stream is the critical path of the workgroup:
+      // everything a key needs besides the exchange itself is 4 VALU
+      // instructions before it and the conversion of the returned table value
+      // into a chain entry after it.
+      uint32_t *bufp = buf + (par ^ 1) * KX_SUB + lane;
       uint32_t n = lane < (uint32_t)KX_PROD_WAVES ? cnt[(par ^ 1) * 16 + lane] : 0u;
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) n += __shfl_xor(n, o);
       n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
-      const uint32_t sbp = sb - KX_SUB;
-      constexpr int U = 4; // batches in flight
+      const uint32_t vbase = (sb - KX_SUB) << cb; // table value = vbase + low key bits
+      const uint32_t low_mask = (1u << KX_KEY_IDX_SHIFT) - 1;
+      auto convert = [&](uint32_t k, uint32_t old) -> uint32_t {
+        const uint32_t val = vbase + (k & low_mask);
+        // a predecessor at or below the buffer origin counts as "empty" (m4.go:152, 92-98)
+        const uint32_t pos = val >> cb, pp = old >> cb, pck = old & cmask;
+        const uint32_t org = STREAM ? (pos >= p_org_next_x ? p_org_next : p_org_cur) : 0u;
+        // check bits 0 = unknown (entry loaded from a persistent table): may be equal
+        return pp > org ? ((pos - pp) | ((pck == 0 || pck == (val & cmask)) ? kChainMaybe : 0u)) : 0u;
+      };
+      uint32_t e0 = 0;
 #pragma unroll 1
-      for (uint32_t e0 = 0; e0 < n; e0 += 64 * U) {
-        uint32_t k[U], old[U];
+      for (; e0 + 64 * KX_U <= n; e0 += 64 * KX_U) { // full batches: no masking
+        uint32_t k[KX_U], old[KX_U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const uint32_t e = e0 + u * 64 + lane;
-          k[u] = e < n ? bufp[e] : 0u;
-        }
+        for (int u = 0; u < KX_U; u++) k[u] = bufp[e0 + u * 64];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const uint32_t e = e0 + u * 64 + lane;
-          const uint32_t pos = sbp + ((k[u] >> KX_KEY_REL_SHIFT) & KX_KEY_REL_MASK);
-          old[u] = 0;
-          if (e < n)
-            old[u] = __hip_atomic_exchange(&table[k[u] >> KX_KEY_IDX_SHIFT], (pos << cb) | (k[u] & cmask),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        for (int u = 0; u < KX_U; u++)
+          old[u] = __hip_atomic_exchange(&table[k[u] >> KX_KEY_IDX_SHIFT], vbase + (k[u] & low_mask),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const uint32_t e = e0 + u * 64 + lane;
-          const uint32_t pos = sbp + ((k[u] >> KX_KEY_REL_SHIFT) & KX_KEY_REL_MASK);
-          // a predecessor at or below the buffer origin counts as "empty" (m4.go:152, 92-98)
-          const uint32_t pp = old[u] >> cb, pck = old[u] & cmask;
-          const uint32_t org = STREAM ? (pos >= p_org_next_x ? p_org_next : p_org_cur) : 0u;
-          // check bits 0 = unknown (entry loaded from a persistent table): may be equal
-          const uint32_t res = pp > org ? ((pos - pp) | ((pck == 0 || pck == (k[u] & cmask)) ? kChainMaybe : 0u)) : 0u;
-          if (e < n) bufp[e] = res;
-        }
+        for (int u = 0; u < KX_U; u++) bufp[e0 + u * 64] = convert(k[u], old[u]);
+      }
+#pragma unroll 1
+      for (; e0 < n; e0 += 64) { // the rest, one batch at a time
+        const bool act = e0 + lane < n;
+        const uint32_t k = act ? bufp[e0] : 0u;
+        uint32_t old = 0;
+        if (act)
+          old = __hip_atomic_exchange(&table[k >> KX_KEY_IDX_SHIFT], vbase + (k & low_mask),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (act) bufp[e0] = convert(k, old);
       }
     }
-    lds_barrier(); // wave counts of tile t complete; everybody is done with the tile image and with bufc
+    lds_barrier(); // wave counts of tile t complete; chain entries of tile t-1 in place
     if (!consumer && t < ntiles) {
       // ordered compaction: queue slot = keys of earlier waves + of earlier rows + of earlier lanes
       uint32_t c = lane < (uint32_t)KX_PROD_WAVES ? cnt[par * 16 + lane] : 0u;
@@ -240,13 +257,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
     }
     in2 = in1;
     in1 = in0;
-    // stage the next tile image and start fetching the one after it
-    if (tid < KX_GROUPS && t + 1 < ntiles) {
-      reinterpret_cast<uint4 *>(img)[tid] = pre;
-      if (t + 2 < ntiles)
-        pre = load_group(src_base, tile_origin(sb + 2 * KX_SUB) + 16 * (int64_t)tid, (int64_t)src_total);
-    }
-    lds_barrier(); // keys of tile t queued, next image staged
+    lds_barrier(); // keys of tile t queued
   }
 
   if (store_table) { // entries relative to the origin after the call, at or below it = empty

@@ -62,6 +62,7 @@ ParseParams parse_params(const Params &p) {
 }
 
 constexpr int kMaxPartBits = 15; // 2^15 * 4 B = 128 KiB of LDS
+constexpr int kK1MaxTile = K1_SUB > KX_SUB ? K1_SUB : KX_SUB; // positions per K1 tile, either kernel
 
 int part_bits_of(const Params &p) { return std::min(p.table_bits, kMaxPartBits); }
 
@@ -929,7 +930,7 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
   // The one-launch path needs: more than one block, at most one block end and
   // one slide per K1 tile, and a bounded slide list.  Otherwise: block by block.
   const uint64_t W = (uint64_t)p.max_distance;
-  const bool fast = nblocks >= 2 && block_size >= (size_t)K1_SUB + 7 && W >= (uint64_t)K1_SUB &&
+  const bool fast = nblocks >= 2 && block_size >= (size_t)kK1MaxTile + 7 && W >= (uint64_t)kK1MaxTile &&
                     n / W + 2 < (size_t)kStreamMaxSlides && nblocks < ((size_t)1 << 24);
   if (!fast) {
     int64_t total = 0;
