@@ -9,8 +9,9 @@
 //     address are performed in ascending lane order
 //     (tools/probes/lds_xchg_order.hip: 134 M exchanges, 78 M of them behind an
 //     earlier lane of the same instruction, 0 deviations; libm4g repeats a short
-//     form of the probe when a context or plan is created and falls back to the
-//     sorting kernel if it ever fails);
+//     form of the probe -- kx_order_selftest below -- once per device when a
+//     context or plan is created and uses the sorting kernel k1_chain_build
+//     instead if it ever fails);
 //   * the LDS instructions of one wave are performed in program order.
 // So the keys of a tile only have to reach ONE wave in position order:
 //   * 15 PRODUCER waves hash the tile.  Wave w owns KX_WAVE_SPAN consecutive
@@ -54,6 +55,43 @@ constexpr size_t k1x_lds_bytes(int part_bits) {
   return ((size_t)1 << part_bits) * 4 + 2 * (size_t)KX_SUB * 4 + 2 * 16 * 4;
 }
 static_assert(k1x_lds_bytes(15) <= 160 * 1024, "LDS of one CU");
+
+// Self-test of the ordering k1x_chain_build relies on (run once per device when
+// a context or plan is created): 4 waves x 64 exchange instructions whose lanes
+// collide on purpose; a lane must get the value of the nearest lower lane of the
+// same instruction with the same address, or the entry's earlier content, and
+// the entry must end up with the value of the highest such lane.
+__global__ __launch_bounds__(256) void kx_order_selftest(uint32_t *__restrict__ mismatches) {
+  __shared__ uint32_t tab[4][64];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *t = tab[wave];
+  t[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t bad = 0;
+  for (uint32_t it = 0; it < 64; it++) {
+    const uint32_t range = 1u + (it * 7u + wave * 3u) % 64u;       // 1 .. 64 distinct addresses
+    const uint32_t idx = ((lane + it) * 2654435761u >> 7) % range; // many lanes per address
+    const uint32_t val = (it << 8 | lane) + 1;
+    const uint32_t before = t[idx];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t got = __hip_atomic_exchange(&t[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t after = t[idx];
+    uint32_t expect = before, expect_after = val;
+    for (uint32_t l = 0; l < 64; l++) {
+      const uint32_t li = __shfl(idx, l), lv = __shfl(val, l);
+      if (li == idx && l < lane) expect = lv;
+      if (li == idx && l > lane) expect_after = lv;
+    }
+    if (got != expect || after != expect_after) bad++;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
 
 template <bool STREAM>
 __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -83,7 +84,9 @@ int check_device(int device) {
   return M4G_OK;
 }
 
+int k1_selftest();
 int k1_prepare() {
+  if (int rc = k1_selftest()) return rc;
   // > 64 KiB of dynamic LDS needs the attribute once per device.
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1_chain_build<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -100,10 +103,35 @@ int k1_prepare() {
   return M4G_OK;
 }
 
-// K1 variant: the exchange kernel (k1_xchg.h) unless M4G_K1_SORT is set
+// K1 variant: the exchange kernel (k1_xchg.h), unless M4G_K1_SORT is set or the
+// device failed the ordering self-test (then the sorting kernel, kernels.h).
+std::atomic<int> g_xchg_order[64]; // per device: 0 = not tested, 1 = ordered, 2 = not ordered
 bool k1_use_sort() {
-  static const bool v = std::getenv("M4G_K1_SORT") != nullptr;
-  return v;
+  static const bool forced = std::getenv("M4G_K1_SORT") != nullptr;
+  if (forced) return true;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  return g_xchg_order[dev].load() == 2;
+}
+int k1_selftest() {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || g_xchg_order[dev].load() != 0) return M4G_OK;
+  uint32_t *d = nullptr, h = 0;
+  HIP_TRY(hipMalloc(&d, 4));
+  hipError_t e = hipMemset(d, 0, 4);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(kx_order_selftest, dim3(8), dim3(256), 0, nullptr, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
+  g_xchg_order[dev].store(h == 0 ? 1 : 2);
+  if (h != 0)
+    std::fprintf(stderr, "[m4g] device %d: LDS exchange is not lane ordered (%u deviations); K1 uses the sorting kernel\n",
+                 dev, h);
+  return M4G_OK;
 }
 
 // Device buffers of the speculative parse (kernels.h, K3) for up to `blocks`
@@ -470,6 +498,16 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
   HIP_TRY(hipEventElapsedTime(ms_out, b->ev[0], b->ev[1]));
   *ms_out /= (float)reps;
   return M4G_OK;
+}
+
+// Diagnostic (not part of include/m4g.h): which K1 kernel the device gets --
+// 1 = ordered LDS exchange (k1_xchg.h), 0 = sorting kernel.
+extern "C" int m4g_debug_k1_variant(int device) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  if ((rc = k1_prepare())) return rc;
+  return k1_use_sort() ? 0 : 1;
 }
 
 extern "C" int m4g_batch_last_timings(m4g_batch *b, float *ms, int cap) {

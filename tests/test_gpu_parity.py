@@ -253,3 +253,13 @@ def test_cpp_host_mirror():
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sim", "host_mirror_check")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_k1_uses_the_exchange_kernel_on_this_device():
+    """libm4g checks at create time that the lanes of one LDS exchange
+    instruction are performed in lane order (k1_xchg.h) and would fall back to
+    the sorting kernel otherwise; on gfx950 the check passes."""
+    import os
+    L = m4.lib()
+    v = L.m4g_debug_k1_variant(0)
+    assert v == (0 if os.environ.get("M4G_K1_SORT") else 1), v
