@@ -361,14 +361,27 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
         }
       }
     }
+    // m4.go:166-181.  The chain entry of a candidate and the bytes around it are
+    // read together (one far round trip per hop instead of two dependent ones).
+    uint32_t next_entry = P.chain_length > 0 ? M.chain_at(cand) : 0u;
     for (int32_t j = 0; j < P.chain_length; j++) {
-      uint32_t dd = M.chain_at(cand) & kChainDelta;
+      uint32_t dd = next_entry & kChainDelta;
       if (dd == 0) break;
       // Go: candidate -= int(delta) in 64-bit; dd > cand means candidate <= 0
       if (dd >= (uint32_t)cand) break;
       cand -= (int32_t)dd;
       if (i - cand > P.max_distance) break;
-      if (match_at(M, len, i, cand, S.next_emit, m)) {
+      bool hop_hit;
+      if (cand >= 8) { // i + 8 <= len always
+        const bool two = i + 16 <= len;
+        next_entry = M.chain_at(cand);
+        const uint64_t hf = M.far64(cand), hb = M.far64(cand - 8), hf2 = M.far64(two ? cand + 8 : cand);
+        hop_hit = match_regs(M, len, i, cand, S.next_emit, hf, hf2, two, hb, m);
+      } else {
+        next_entry = M.chain_at(cand);
+        hop_hit = match_at(M, len, i, cand, S.next_emit, m);
+      }
+      if (hop_hit) {
         if (!S.have_prev && m.start == S.next_emit) S.error |= kStateHitLo;
         if (m.end >= len) S.error |= kStateTouchedEnd;
         if (m.end - m.start > P.min_length) {
