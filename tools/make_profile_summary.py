@@ -72,8 +72,12 @@ for k in sorted(set(F) | set(W)):
         L.append(f"| {k} | {F.get(k, 0)*1024/1e9:.2f} | {F.get(k, 0)*2048/1e9:.2f} | {W.get(k, 0)*1024/1e9:.2f} |")
 L.append("\nReading: K1 moves exactly what it must (1 B/B source read once from HBM, the other three partition workgroups hit L2;")
 L.append("4 B/B chain written as full lines).  K3a still reads many times the chain+source bytes: the staged windows are re-fetched")
-L.append("every 16 positions (L2 hit rate 11 %) and match sources are random sector reads.  SQ counters (`--pmc SQ_*`, earlier run):")
-L.append("K1 VALU-busy 56 %, K3a VALU-busy 57 % with 26 % of lanes active per instruction (divergence of 64 independent parses),")
-L.append("69 % of wave time waiting.")
+L.append("every 16 positions (L2 hit rate 11 %) and match sources are random sector reads.")
+L.append("SQ counters (`scratch/pmc_k1.sh`, `scratch/pmc_k3.sh`; quad-cycles summed over waves): both big kernels are bound by")
+L.append("instruction issue, not by memory.  K1 (exchange kernel): a wave issues in 25 % of its cycles, 4 waves per SIMD = 100 %;")
+L.append("VALU 59 % of SIMD time, SALU 25 %, LDS pipeline busy 57 %.  K3a: a wave issues in 26 % of its cycles (x 4 waves per SIMD),")
+L.append("waits in 68 %; VALU instructions run with 26 % of their lanes active (64 independent parses per wave), SALU is 31 % of")
+L.append("all instructions (divergent control flow).  More waves do not help K3a (5 or 6 per SIMD with spills: 11.6 / 12.6 ms against")
+L.append("11.3 ms per GiB), fewer hurt (2 per SIMD: 16.8 ms).")
 open(P(f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[:14]))
