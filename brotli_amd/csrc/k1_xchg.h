@@ -146,11 +146,18 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
   // (positions past the buffer read its last 8 bytes; they are never used)
   const uint32_t my_rel = wave * KX_WAVE_SPAN + lane; // row 0
   auto load_windows = [&](uint32_t base, uint2 *v) {
+    const uint64_t a0 = J.src_off + base; // wave-uniform
+    if (a0 + KX_SUB + 8 <= src_total) { // whole tile inside the buffer: scalar base + lane offset
+      const uint8_t *tp = src_base + a0;
 #pragma unroll
-    for (int j = 0; j < KX_PER; j++) {
-      uint64_t a = J.src_off + base + my_rel + j * 64;
-      if (a + 8 > src_total) a = src_total - 8;
-      __builtin_memcpy(&v[j], src_base + a, 8);
+      for (int j = 0; j < KX_PER; j++) __builtin_memcpy(&v[j], tp + (my_rel + j * 64), 8);
+    } else {
+#pragma unroll
+      for (int j = 0; j < KX_PER; j++) {
+        uint64_t a = a0 + my_rel + j * 64;
+        if (a + 8 > src_total) a = src_total - 8;
+        __builtin_memcpy(&v[j], src_base + a, 8);
+      }
     }
   };
   uint2 vn[KX_PER]; // windows of the next tile
@@ -190,20 +197,26 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
 
     uint32_t key[KX_PER], in0 = 0;
     unsigned long long bal[KX_PER];
+    bool inr[KX_PER]; // row j of this lane has a key for this partition
+#pragma unroll
+    for (int j = 0; j < KX_PER; j++) inr[j] = false;
     if (!consumer) {
       uint2 v[KX_PER];
 #pragma unroll
       for (int j = 0; j < KX_PER; j++) v[j] = vn[j];
       if (t + 1 < ntiles) load_windows(sb + KX_SUB, vn);
-      // chain entries of tile t-2 (the consumer finished it one iteration ago)
-      if (t >= 2 && !(dbg & 1)) {
-        const uint32_t p0 = sb - 2 * KX_SUB + my_rel;
+      // chain entries of tile t-2 (the consumer finished it one iteration ago):
+      // read now, stored after the hashing below has covered the LDS latency
+      // (slots of rows without a key are <= KX_SUB: inside the LDS image)
+      const bool pickup = t >= 2 && !(dbg & 1);
+      uint32_t ce[KX_PER];
+      if (pickup) {
 #pragma unroll
-        for (int j = 0; j < KX_PER; j++)
-          if ((in2 >> j & 1) && p0 + j * 64 >= store_from) chain[p0 + j * 64] = bufc[slot2[j]];
+        for (int j = 0; j < KX_PER; j++) ce[j] = bufc[slot2[j]];
       }
       // hash tile t
       uint32_t total = 0;
+      const uint32_t lim = end > sb ? end - sb : 0u; // positions of the tile below this are inserted
       if (t < ntiles && !(dbg & 4)) {
 #pragma unroll
         for (int j = 0; j < KX_PER; j++) {
@@ -211,17 +224,25 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
           const uint32_t lo = v[j].x & mask_lo, hi = v[j].y & mask_hi;
           const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
           const uint32_t pos = sb + rel;
-          const bool in = pos < end && (h >> part_bits) == q &&
+          const bool in = rel < lim && (h >> part_bits) == q &&
                           !(STREAM && pos + 7 >= blk_end && pos < blk_end);
           // check bits of the first 4 bytes (never 0: that value marks table
-          // entries whose bytes are not known)
-          const uint32_t ck = cb ? max(1u, (v[j].x * 0x9E3779B1u) >> (32 - cb)) : 0u;
+          // entries whose bytes are not known); cb >= 1 (launch_k1)
+          const uint32_t ck = max(1u, (v[j].x * 0x9E3779B1u) >> (32 - cb));
           // the low 17 key bits + (tile start << cb) are the table value of the position
           key[j] = ((h & idx_mask) << KX_KEY_IDX_SHIFT) | (rel << cb) | ck;
-          bal[j] = __ballot(in);
+          inr[j] = in;
+          bal[j] = __builtin_amdgcn_ballot_w64(in);
           if (in) in0 |= 1u << j;
           total += (uint32_t)__builtin_popcountll(bal[j]);
         }
+      }
+      if (pickup) {
+        uint32_t *cp = chain + (sb - 2 * KX_SUB); // wave-uniform
+#pragma unroll
+        for (int j = 0; j < KX_PER; j++)
+          if ((in2 >> j & 1) && (!STREAM || sb - 2 * KX_SUB + my_rel + j * 64 >= store_from))
+            cp[my_rel + j * 64] = ce[j];
       }
       if (lane == 0) cnt[par * 16 + wave] = total;
     } else if (t >= 1 && t - 1 < ntiles && !(dbg & 2)) {
@@ -272,21 +293,20 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
     lds_barrier(); // wave counts of tile t complete; chain entries of tile t-1 in place
     if (!consumer && t < ntiles) {
       // ordered compaction: queue slot = keys of earlier waves + of earlier rows + of earlier lanes
-      uint32_t c = lane < (uint32_t)KX_PROD_WAVES ? cnt[par * 16 + lane] : 0u;
-      uint32_t incl = c;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o);
-        if (lane >= (uint32_t)o) incl += up;
-      }
-      uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(incl - c), (int)wave);
+      // keys of the waves before this one: sum of cnt[0 .. wave) over lanes 0..15 of row 0
+      uint32_t c = lane < wave ? cnt[par * 16 + (lane & 15)] : 0u;
+      c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x111, 0xf, 0xf, true); // row_shr:1
+      c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x112, 0xf, 0xf, true); // row_shr:2
+      c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x114, 0xf, 0xf, true); // row_shr:4
+      c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x118, 0xf, 0xf, true); // row_shr:8
+      uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)c, 15);
 #pragma unroll
       for (int j = 0; j < KX_PER; j++) {
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[j] >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bal[j], 0u));
         slot2[j] = slot1[j];
-        slot1[j] = base + below;
-        if (in0 >> j & 1) bufc[slot1[j]] = key[j];
+        // keys of earlier waves and rows + keys of the lanes below
+        slot1[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[j] >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((uint32_t)bal[j], base));
+        if (inr[j]) bufc[slot1[j]] = key[j];
         base += (uint32_t)__builtin_popcountll(bal[j]);
       }
     } else {

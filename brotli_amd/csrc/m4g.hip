@@ -203,6 +203,7 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
   int posbits = 1;
   while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
   const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
+  if (cb < 1 && !k1_use_sort()) return fail(M4G_ERR_TOO_LARGE, "buffer positions need all 32 bits");
   if (!k1_use_sort()) {
     if (d_si)
       hipLaunchKernelGGL(k1x_chain_build<true>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), st, d_src, src_total, d_chain,
