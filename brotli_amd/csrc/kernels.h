@@ -1146,7 +1146,10 @@ __device__ __forceinline__ uint32_t distance_symbol(uint32_t distance) {
   return 2 * (nbits - 1) + prefix + 16;
 }
 
-constexpr int K5_THREADS = 256;
+#ifndef M4G_K5_THREADS
+#define M4G_K5_THREADS 512
+#endif
+constexpr int K5_THREADS = M4G_K5_THREADS;
 constexpr int K5_WAVES = K5_THREADS / 64;
 
 // Up to four most recent flagged distances, most recent first.
@@ -1212,17 +1215,28 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
 
   uint32_t *mylit = lit[wid];
   uint32_t par = 0;
+  // this thread's match of the next iteration (and, for lane 0, the distance
+  // of the match before it), loaded one iteration ahead: the records are the
+  // head of every iteration's dependency chain
+  uint32_t nx_un = 0, nx_len = 0, nx_dist = 0, nx_prev = 0xFFFFFFFFu;
+  auto load_rec = [&](uint32_t jj) {
+    nx_un = nx_len = nx_dist = 0;
+    nx_prev = 0xFFFFFFFFu;
+    if (jj < n) {
+      nx_un = rec[3 * jj];
+      nx_len = rec[3 * jj + 1];
+      nx_dist = rec[3 * jj + 2];
+      if (lane == 0 && jj > 0) nx_prev = rec[3 * jj - 1];
+    }
+  };
+  load_rec((uint32_t)tid);
   for (uint32_t base = 0; base < n; base += K5_THREADS, par ^= 1) {
     const uint32_t j = base + tid;
-    uint32_t un = 0, len = 0, dist = 0;
-    if (j < n) {
-      un = rec[3 * j];
-      len = rec[3 * j + 1];
-      dist = rec[3 * j + 2];
-    }
+    const uint32_t un = nx_un, len = nx_len, dist = nx_dist, prev0 = nx_prev;
+    load_rec(j + K5_THREADS);
     // distance of the previous match (none before the first)
     uint32_t prevd = __shfl_up(dist, 1);
-    if (lane == 0) prevd = (j > 0 && j < n) ? rec[3 * j - 1] : 0xFFFFFFFFu;
+    if (lane == 0) prevd = prev0;
     const bool flag = j < n && len != 0 && dist != prevd;
     const bool use_last = j < n && dist == prevd;
 
