@@ -250,6 +250,9 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
         },
     }
+    # rate of the measured HBM-side traffic (GB/s): how close the kernel's REAL bytes are to the peak
+    tr = out["roofline"]["traffic"]
+    out["roofline"]["traffic_rate"] = round(tr / (stage_ms[dom] * 1e-3), 1) if tr and stage_ms[dom] > 0 else None
     if not args.no_cpu_baseline and world == 1:
         threads = max(1, min(16, os.cpu_count() or 1))
         sample = min(C, args.cpu_sample_chunks)

@@ -63,21 +63,21 @@ L.append(f"* inputs that defeat the speculation: `profiles/{tag}_kind_probe.log`
 L.append("## HBM-side traffic (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, 1024 x 1 MiB text chunks, per launch)\n")
 L.append("FETCH_SIZE/WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies 128-byte requests")
 L.append("at 64 bytes, so the read column is doubled; `profiles/traffic.json` (made by `tools/pmc_traffic.py`, read by bench.py")
-L.append("for `roofline.traffic`) holds the corrected bytes per input byte.  The guide calibrates the factor on wide streaming")
-L.append("reads only; K3a mixes those with 8-byte random reads, so its corrected figure is an upper bound.")
+L.append("for `roofline.traffic`) holds the corrected bytes per input byte.  A request-size pass (`tools/pmc_one.sh`:")
+L.append("TCC_EA0_RDREQ = TCC_EA0_RDREQ_128B, 188-211 M per 0.5 GiB launch, none of 32 or 64 bytes) confirms the factor for K3a too.")
 L.append("Algorithmic bytes of this launch: N + 12 M + 4096/chunk = 1.07 GB + 1.09 GB + 4 MiB = 2.16 GB.\n")
 L.append("| kernel | FETCH_SIZE GB (raw) | x2 | WRITE_SIZE GB |\n|---|---|---|---|")
 for k in sorted(set(F) | set(W)):
     if "m4g" in k:
         L.append(f"| {k} | {F.get(k, 0)*1024/1e9:.2f} | {F.get(k, 0)*2048/1e9:.2f} | {W.get(k, 0)*1024/1e9:.2f} |")
 L.append("\nReading: K1 moves exactly what it must (1 B/B source read once from HBM, the other three partition workgroups hit L2;")
-L.append("4 B/B chain written as full lines).  K3a still reads many times the chain+source bytes: the staged windows are re-fetched")
-L.append("every 16 positions (L2 hit rate 11 %) and match sources are random sector reads.")
-L.append("SQ counters (`scratch/pmc_k1.sh`, `scratch/pmc_k3.sh`; quad-cycles summed over waves): both big kernels are bound by")
-L.append("instruction issue, not by memory.  K1 (exchange kernel): a wave issues in 25 % of its cycles, 4 waves per SIMD = 100 %;")
-L.append("VALU 59 % of SIMD time, SALU 25 %, LDS pipeline busy 57 %.  K3a: a wave issues in 26 % of its cycles (x 4 waves per SIMD),")
-L.append("waits in 68 %; VALU instructions run with 26 % of their lanes active (64 independent parses per wave), SALU is 31 % of")
-L.append("all instructions (divergent control flow).  More waves do not help K3a (5 or 6 per SIMD with spills: 11.6 / 12.6 ms against")
-L.append("11.3 ms per GiB), fewer hurt (2 per SIMD: 16.8 ms).")
+L.append("4 B/B chain written as full lines) and is bound by the instruction count of its 15 producer waves, which run in lockstep")
+L.append("phases between two barriers per tile (`tools/k1_probe.py`: consumer off 8.1 of 8.6 ms per GiB, loads + barriers alone 5.6).")
+L.append("K3a is bound by its memory traffic: ~50 bytes fetched per input byte, all as 128-byte lines, L2 hit rate 9 %, 5.0 TB/s at the")
+L.append("L2-fabric interface -- the random-gather ceiling of this HBM (MI355X_MICROARCH.md: 5.5-5.8 TB/s for random 1 KiB rows).")
+L.append("Window staging is ~16 % of the lines, candidate reads ~45 %, repeat-probe reads ~25 %; every 8-24 byte read of a match")
+L.append("source costs a line, and 32768 independent lanes per XCD share a 4 MiB L2 (DESIGN.md section 5 lists what was tried).")
+L.append("VALU 39 % busy, TA 41 % busy (`tools/pmc_mem.sh`).  More waves do not help K3a (5 or 6 per SIMD with spills: 11.6 / 12.6 ms")
+L.append("against 11.3 ms per GiB), fewer hurt (2 per SIMD: 16.8 ms).")
 open(P(f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L[:14]))

@@ -8,7 +8,7 @@
 constexpr int TBL = 32768;
 
 template <int MODE, int U>
-__global__ __launch_bounds__(1024) void probe(uint32_t *out, uint64_t *ticks, int iters, int busy_waves) {
+__global__ __launch_bounds__(1024) void probe(uint32_t *out, uint64_t *ticks, int iters, int busy_waves, int runlen) {
   extern __shared__ uint32_t table[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int k = tid; k < TBL; k += blockDim.x) table[k] = k;
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(1024) void probe(uint32_t *out, uint64_t *ticks, in
     }
     return;
   }
-  uint32_t s = lane * 2654435761u + blockIdx.x, acc = 0;
+  // lanes in groups of `runlen` share one table entry (runlen 1: all different)
+  uint32_t s = (lane / (uint32_t)runlen) * 2654435761u + blockIdx.x, acc = 0;
   const uint64_t t0 = wall_clock64();
   for (int it = 0; it < iters; it++) {
     uint32_t idx[U], val[U], old[U], chk[U];
@@ -60,18 +61,18 @@ __global__ __launch_bounds__(1024) void probe(uint32_t *out, uint64_t *ticks, in
 }
 
 template <int MODE, int U>
-void run(const char *name, int busy) {
+void run(const char *name, int busy, int runlen = 1) {
   const int blocks = 256, iters = 4096;
   uint32_t *d_out; uint64_t *d_t;
   hipMalloc(&d_out, blocks * 1024 * 4); hipMalloc(&d_t, blocks * 8);
   hipFuncSetAttribute((const void *)probe<MODE, U>, hipFuncAttributeMaxDynamicSharedMemorySize, TBL * 4);
   for (int rep = 0; rep < 2; rep++)
-    hipLaunchKernelGGL((probe<MODE, U>), dim3(blocks), dim3(1024), TBL * 4, 0, d_out, d_t, iters, busy);
+    hipLaunchKernelGGL((probe<MODE, U>), dim3(blocks), dim3(1024), TBL * 4, 0, d_out, d_t, iters, busy, runlen);
   if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", name); return; }
   uint64_t t[256]; hipMemcpy(t, d_t, sizeof(t), hipMemcpyDeviceToHost);
   double sum = 0; for (int b = 0; b < blocks; b++) sum += (double)t[b];
   const double ns = sum / blocks * 10.0 / ((double)iters * U); // wall_clock64: 100 MHz
-  printf("%-34s U=%d busy=%2d  %7.1f ns per 64-lane row  (~%5.0f cycles at 2.4 GHz)\n", name, U, busy, ns, ns * 2.4);
+  printf("%-22s U=%d busy=%2d same-address run %2d  %7.1f ns per 64-lane row  (~%5.0f cycles at 2.4 GHz)\n", name, U, busy, runlen, ns, ns * 2.4);
   hipFree(d_out); hipFree(d_t);
 }
 
@@ -84,5 +85,6 @@ int main() {
     run<1, 10>("read+write+readback", busy);
     run<2, 5>("read+write", busy);
   }
+  for (int runlen : {2, 4, 16, 64}) run<0, 5>("xchg_rtn", 0, runlen);
   return 0;
 }
