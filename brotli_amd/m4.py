@@ -341,10 +341,38 @@ class BatchPlan:
         _check(rc, "m4g_batch_run_device")
 
 
+class PinnedBuffer:
+    """Page-locked host memory from m4g_host_alloc, as a numpy array (`.array`).
+    Copies between such a buffer and the GPU run at PCIe speed; pageable memory
+    (numpy's own) is staged by the HIP runtime at a fraction of it, and a fresh
+    numpy output array pays a page fault per 4 KiB on top."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        self._ptr = lib().m4g_host_alloc(self.nbytes)
+        if not self._ptr:
+            raise M4GError("m4g_host_alloc failed")
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=np.uint8)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            lib().m4g_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def find_matches_batch(base, chunk_off: Sequence[int], devices: Sequence[int] = (0,),
-                       want_histos: bool = False, **m4_fields):
+                       want_histos: bool = False, out: "np.ndarray | None" = None, **m4_fields):
     """Host-memory batch (m4g_find_matches_batch): returns (matches[M,3],
-    out_off[nchunks+1], histos[nchunks,1024] or None)."""
+    out_off[nchunks+1], histos[nchunks,1024] or None).  `out`: optional
+    caller-provided uint32 array for the matches (e.g. a view of a PinnedBuffer)."""
     a = _as_u8(base)
     off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
     n = off.size - 1
@@ -353,7 +381,12 @@ def find_matches_batch(base, chunk_off: Sequence[int], devices: Sequence[int] = 
                 m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
     min_len = p.min_length or 4
     cap = int(sum(int(off[c + 1] - off[c]) // min_len + 2 for c in range(n))) + 1
-    out = np.empty((cap, 3), dtype=np.uint32)
+    if out is None:
+        out = np.empty((cap, 3), dtype=np.uint32)
+    else:
+        assert out.dtype == np.uint32 and out.flags.c_contiguous
+        out = out.reshape(-1)[:out.size // 3 * 3].reshape(-1, 3)
+        cap = out.shape[0]
     out_off = np.zeros(n + 1, dtype=np.uint64)
     histos = np.zeros((max(n, 1), 1024), dtype=np.uint32) if want_histos else None
     devs = (ctypes.c_int * len(devices))(*devices)

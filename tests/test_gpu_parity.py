@@ -1,5 +1,6 @@
 """GPU parity: the HIP path (through the C-ABI) vs the CPU oracle, bit-exact."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -125,6 +126,46 @@ def test_batch_host_api_ragged():
         lit, cmd, dist, _, _ = histograms(chunk, ref)
         assert (histos[c, :256] == lit).all() and (histos[c, 256:960] == cmd).all() \
             and (histos[c, 960:] == dist).all()
+
+
+def test_batch_host_api_pipelined_slices():
+    """m4g_find_matches_batch with one device and >= 256 chunks cuts the batch
+    into slices whose copies overlap the kernels: same result as the unsliced
+    call and as the oracle, ragged sizes incl. empty chunks, pinned and pageable
+    output, and the -(needed) answer when the output is too small."""
+    rng = np.random.default_rng(7)
+    sizes = [int(x) for x in rng.choice([0, 7, 100, 3000, 9000, 20000], 300)]
+    sizes[5] = 70001
+    blob = b"".join(synth.text(s, 900 + i) for i, s in enumerate(sizes))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    os.environ["M4G_PIPE_SLICE"] = "100"  # three slices, the last one short (the default slices hold >= 256 chunks)
+    try:
+        _run_pipelined_checks(blob, off, sizes)
+    finally:
+        del os.environ["M4G_PIPE_SLICE"]
+
+
+def _run_pipelined_checks(blob, off, sizes):
+    out, out_off, histos = m4.find_matches_batch(blob, off, (0,), True, **PARAMS_G)
+    os.environ["M4G_NO_PIPELINE"] = "1"
+    try:
+        out1, out_off1, histos1 = m4.find_matches_batch(blob, off, (0,), True, **PARAMS_G)
+    finally:
+        del os.environ["M4G_NO_PIPELINE"]
+    assert (out_off == out_off1).all() and same(out, out1) and (histos == histos1).all()
+    for c in list(range(0, 300, 13)) + [5, 127, 128, 255, 256, 299]:
+        chunk = blob[int(off[c]):int(off[c + 1])]
+        ref = OracleM4(**PARAMS_G).FindMatches(chunk)
+        assert same(out[int(out_off[c]):int(out_off[c + 1])], ref), f"chunk {c}"
+        lit, cmd, dist, _, _ = histograms(chunk, ref)
+        assert (histos[c, :256] == lit).all() and (histos[c, 256:960] == cmd).all() \
+            and (histos[c, 960:] == dist).all()
+    pin = m4.PinnedBuffer(12 * (out.shape[0] + 10))
+    out2, out_off2, _ = m4.find_matches_batch(blob, off, (0,), False, out=pin.array.view(np.uint32), **PARAMS_G)
+    assert (out_off2 == out_off).all() and same(out2, out)
+    with pytest.raises(m4.M4GError, match=f"need {out.shape[0]}"):
+        m4.find_matches_batch(blob, off, (0,), False, out=np.empty(3 * (out.shape[0] - 1), dtype=np.uint32), **PARAMS_G)
+    pin.close()
 
 
 @pytest.mark.parametrize("kw", [PARAMS_G, PARAMS_D], ids=["G", "D"])
