@@ -55,7 +55,8 @@ L.append(f"\nbench.py (HIP events on the launch stream): stage_ms = {b['stage_ms
          f"({b['roofline']['frac']}), roofline.traffic = {b['roofline']['traffic']} GB, cpu_baseline = "
          f"{b['cpu_baseline']['value']} GB/s on {b['cpu_baseline']['cores']} threads, compression ratio "
          f"{b['config']['compression_ratio']}, {b['config']['roundtrip_checked_chunks']} chunks decoded back to the input "
-         f"with libbrotlidec, end-to-end through the host API (pageable memory, PCIe both ways) {e2e.get('value')} GB/s.\n")
+         f"with libbrotlidec, end-to-end through the host API (PCIe both ways) {e2e.get('value')} GB/s from pageable memory, "
+         f"{e2e.get('value_pinned')} GB/s from m4g_host_alloc buffers; roofline.traffic_rate = {b['roofline'].get('traffic_rate')} GB/s.\n")
 L.append("Other workloads (1024 x 1 MiB chunks, same run):\n")
 L.append(f"* low-entropy binary log, params G (BASELINE config 5): {bl['value']} GB/s, stage_ms {bl['stage_ms']}, ratio {bl['config']['compression_ratio']}")
 L.append(f"* text, params D (ChainLength 64, HashLen 5; BASELINE config 4): {bd['value']} GB/s, stage_ms {bd['stage_ms']}, ratio {bd['config']['compression_ratio']}")
