@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--kind", choices=["text", "log"], default="text")
     ap.add_argument("--no-histos", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=384)
+    ap.add_argument("--cpu-sample-chunks", type=int, default=2048)
     ap.add_argument("--verify-chunks", type=int, default=8)
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--e2e-sample-chunks", type=int, default=512)
