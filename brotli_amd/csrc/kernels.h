@@ -1146,6 +1146,17 @@ __device__ __forceinline__ uint32_t distance_symbol(uint32_t distance) {
   return 2 * (nbits - 1) + prefix + 16;
 }
 
+// One record per match for the encoder's second pass (encoder.go:122-154): the
+// command symbol (encoder.go:57-63) and the match's distCache entry
+// (encoder.go:42, 66-97, 163-177).  Same layout as m4g_code in include/m4g.h.
+struct CodeRec {
+  uint16_t command;
+  uint8_t dist_code; // 0 with n_extra 0 when the match takes no distance code
+  uint8_t n_extra;
+  uint32_t extra_bits;
+};
+static_assert(sizeof(CodeRec) == 8, "m4g_code layout");
+
 #ifndef M4G_K5_THREADS
 #define M4G_K5_THREADS 512
 #endif
@@ -1177,10 +1188,12 @@ __device__ __forceinline__ K5Ring k5_ring_cat(const K5Ring &newer, const K5Ring 
   return r;
 }
 
+// CODES: also write one CodeRec per match (codes[] is indexed like matches[]).
+template <bool CODES>
 __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ matches /* 3 words each */,
     const Job *__restrict__ jobs, const uint64_t *__restrict__ out_off, uint64_t out_cap,
-    uint32_t *__restrict__ histos /* 1024 u32 per job */) {
+    uint32_t *__restrict__ histos /* 1024 u32 per job */, CodeRec *__restrict__ codes) {
   __shared__ uint32_t lit[K5_WAVES][256];
   __shared__ uint32_t cmd[704];
   __shared__ uint32_t dst[64];
@@ -1302,6 +1315,7 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
       uint32_t cc = len ? copy_length_code(len) : 2u;
       uint32_t command = combine_length_codes(ic, cc, use_last);
       atomicAdd(&cmd[command], 1u);
+      CodeRec cr{(uint16_t)command, 0, 0, 0};
       if (command >= 128 && len != 0) {
         const int64_t D = dist, d3 = ring[0];
         uint32_t code;
@@ -1317,7 +1331,16 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
         else if (D == d3 + 3) code = 9;
         else code = distance_symbol(dist);
         atomicAdd(&dst[code], 1u);
+        if (CODES) {
+          cr.dist_code = (uint8_t)code;
+          if (code >= 16) { // getDistanceCode, encoder.go:169-177
+            const uint32_t dd = dist + 3, nbits = log2_floor_nz(dd) - 1;
+            cr.n_extra = (uint8_t)nbits;
+            cr.extra_bits = dd - ((2 + ((dd >> nbits) & 1)) << nbits);
+          }
+        }
       }
+      if (CODES) codes[o0 + j] = cr;
     }
     // literals: short runs per lane (8 bytes per load), long runs by the whole wave
     const bool longrun = un >= 64;

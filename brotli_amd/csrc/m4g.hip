@@ -411,8 +411,18 @@ extern "C" void m4g_batch_set_timing(m4g_batch *b, int enabled) {
 extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const uint64_t *chunk_off,
                                     size_t nchunks, m4g_match *d_out, uint64_t *d_out_off,
                                     size_t out_cap, m4g_histo *d_histos, void *hip_stream) {
+  return m4g_batch_run_device_codes(b, d_src, chunk_off, nchunks, d_out, d_out_off, out_cap, d_histos,
+                                    nullptr, hip_stream);
+}
+
+extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, const uint64_t *chunk_off,
+                                          size_t nchunks, m4g_match *d_out, uint64_t *d_out_off,
+                                          size_t out_cap, m4g_histo *d_histos, m4g_code *d_codes,
+                                          void *hip_stream) {
   if (!b || !chunk_off || !d_out_off || (!d_out && out_cap))
     return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (d_codes && !d_histos)
+    return fail(M4G_ERR_BAD_PARAM, "d_codes needs d_histos (both come from the same pass)");
   if (nchunks > b->max_chunks) return fail(M4G_ERR_TOO_LARGE, "nchunks above the plan's max_chunks");
   if (nchunks && !d_src) return fail(M4G_ERR_BAD_PARAM, "d_src is NULL");
   HIP_TRY(hipSetDevice(b->device));
@@ -464,10 +474,17 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
 
   if (d_histos) {
     static_assert(sizeof(m4g_histo) == 1024 * 4, "m4g_histo layout");
-    hipLaunchKernelGGL(k5_histograms, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
-                       reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
-                       (uint64_t)out_cap,
-                       reinterpret_cast<uint32_t *>(d_histos));
+    static_assert(sizeof(m4g_code) == sizeof(CodeRec), "m4g_code layout");
+    if (d_codes)
+      hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
+                         reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
+                         (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
+                         reinterpret_cast<CodeRec *>(d_codes));
+    else
+      hipLaunchKernelGGL(k5_histograms<false>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
+                         reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
+                         (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
+                         static_cast<CodeRec *>(nullptr));
     HIP_TRY(hipGetLastError());
   }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));

@@ -35,7 +35,8 @@ EXPORTS = [
     "m4g_strerror", "m4g_last_error", "m4g_device_count", "m4g_create", "m4g_destroy",
     "m4g_reset", "m4g_find_matches", "m4g_find_matches_blocks", "m4g_debug_dump_tables",
     "m4g_history_len",
-    "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_find_matches_batch",
+    "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_batch_run_device_codes",
+    "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
 ]
 
@@ -86,6 +87,7 @@ def lib():
         L.m4g_batch_destroy.argtypes = [vp]
         L.m4g_batch_destroy.restype = None
         L.m4g_batch_run_device.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp]
+        L.m4g_batch_run_device_codes.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp, vp]
         L.m4g_find_matches_batch.argtypes = [ctypes.POINTER(Params), vp, vp, sz, vp, ctypes.c_int,
                                              vp, vp, sz, vp]
         L.m4g_find_matches_batch.restype = ctypes.c_int64
@@ -327,13 +329,26 @@ class BatchPlan:
         n = lib().m4g_batch_last_timings(self._h, ms, 4)
         return [float(ms[k]) for k in range(n)]
 
-    def run(self, d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0):
+    def run(self, d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0,
+            d_codes=None):
         """d_src: uint8 tensor; chunk_off: host uint64 array (nchunks+1);
         d_out: int32/uint32-view tensor with 3*out_cap elements; d_out_off:
-        int64 tensor (nchunks+1); d_histos: optional int32 tensor (nchunks*1024)."""
+        int64 tensor (nchunks+1); d_histos: optional int32 tensor (nchunks*1024);
+        d_codes: optional tensor of 8 bytes per record of d_out (m4g_code: u16
+        command, u8 dist_code, u8 n_extra, u32 extra_bits; encoder.go:57-97)."""
         off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
         n = off.size - 1
         out_cap = d_out.numel() * d_out.element_size() // 12
+        if d_codes is not None:
+            if d_codes.numel() * d_codes.element_size() < 8 * out_cap:
+                raise M4GError("d_codes holds fewer records than d_out")
+            rc = lib().m4g_batch_run_device_codes(
+                self._h, d_src.data_ptr(), off.ctypes.data, n, d_out.data_ptr(),
+                d_out_off.data_ptr(), out_cap,
+                d_histos.data_ptr() if d_histos is not None else None, d_codes.data_ptr(),
+                stream if stream else None)
+            _check(rc, "m4g_batch_run_device_codes")
+            return
         rc = lib().m4g_batch_run_device(self._h, d_src.data_ptr(), off.ctypes.data, n,
                                         d_out.data_ptr(), d_out_off.data_ptr(), out_cap,
                                         d_histos.data_ptr() if d_histos is not None else None,

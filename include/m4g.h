@@ -59,6 +59,20 @@ typedef struct {
   uint32_t dist[64];
 } m4g_histo;
 
+/* What pass 2 of brotli.Encoder.Encode (encoder.go:122-154) needs per match
+ * besides the Match itself: the command symbol (encoder.go:57-63, recomputed
+ * by the reference at :124-130) and the match's `distCache` entry
+ * (`distanceCode{code, nExtra, extraBits}`, encoder.go:42, 66-97, 163-177).
+ * A match that takes no distance code (command < 128, or the trailing literal
+ * run with Length 0; encoder.go:67) has dist_code = n_extra = extra_bits = 0 --
+ * the reference leaves a stale entry there and never reads it. */
+typedef struct {
+  uint16_t command;    /* 0..703 */
+  uint8_t dist_code;   /* distanceCode.code: 0..9 ring codes, >= 16 direct */
+  uint8_t n_extra;     /* distanceCode.nExtra */
+  uint32_t extra_bits; /* distanceCode.extraBits */
+} m4g_code;
+
 typedef struct m4g_ctx m4g_ctx;     /* one streaming M4 (one Go `*M4`) */
 typedef struct m4g_batch m4g_batch; /* reusable plan for independent chunks */
 
@@ -164,6 +178,19 @@ int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src,
                          const uint64_t *chunk_off, size_t nchunks,
                          m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
                          m4g_histo *d_histos, void *hip_stream);
+
+/* Same as m4g_batch_run_device, and additionally writes one m4g_code per match
+ * to d_codes (device memory, out_cap records, indexed like d_out): the
+ * per-match results of Encoder.Encode's first pass (encoder.go:44-105) that
+ * its second pass consumes, so a host encoder fed from d_out + d_histos +
+ * d_codes only has to build the three prefix codes and write bits.
+ * d_codes == NULL behaves exactly like m4g_batch_run_device; d_codes without
+ * d_histos is M4G_ERR_BAD_PARAM. */
+int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src,
+                               const uint64_t *chunk_off, size_t nchunks,
+                               m4g_match *d_out, uint64_t *d_out_off,
+                               size_t out_cap, m4g_histo *d_histos,
+                               m4g_code *d_codes, void *hip_stream);
 
 /* Host-memory form over one or more devices: chunk c goes to
  * devices[c % ndevices]; per-chunk Match lists and histograms come back over
