@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--params", choices=sorted(PARAM_SETS), default="G")
     ap.add_argument("--kind", choices=["text", "log"], default="text")
     ap.add_argument("--no-histos", action="store_true")
+    ap.add_argument("--codes", action="store_true",
+                    help="also write the per-match command / distCache records (m4g_batch_run_device_codes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=2048)
     ap.add_argument("--verify-chunks", type=int, default=8)
@@ -134,10 +136,11 @@ def main():
     d_out = torch.empty(3 * out_cap, dtype=torch.int32, device=dev)
     d_off = torch.empty(C + 1, dtype=torch.int64, device=dev)
     d_h = None if args.no_histos else torch.empty(C * 1024, dtype=torch.int32, device=dev)
+    d_codes = torch.empty(2 * out_cap, dtype=torch.int32, device=dev) if args.codes and d_h is not None else None
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
-        plan.run(d_src, off, d_out, d_off, d_h, stream)
+        plan.run(d_src, off, d_out, d_off, d_h, stream, d_codes=d_codes)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -233,6 +236,7 @@ def main():
             "params": args.params,
             "m4": kw,
             "histograms": d_h is not None,
+            "per_match_codes": d_codes is not None,
             "matches_per_MiB": round(total_matches / (C * n / 2**20), 1),
             "parity_checked_chunks": verified,
             "roundtrip_checked_chunks": roundtrips,
@@ -271,7 +275,7 @@ def main():
         # clock from the first H2D enqueue to the last D2H completion (SURVEY
         # 8d "end-to-end").  Reported beside `value`, never as `value`.
         sample = min(C, args.e2e_sample_chunks)
-        del plan, d_out, d_off, d_h, d_src
+        del plan, d_out, d_off, d_h, d_src, d_codes
         torch.cuda.empty_cache()
         sub_off = off[:sample + 1]
         m4.find_matches_batch(host[:n * min(sample, 8)], off[:min(sample, 8) + 1], (local_rank,), True, **kw)  # warm
