@@ -1061,13 +1061,30 @@ __global__ __launch_bounds__(1024) void k4_scan_counts(
   if (tid == 0) out_off[njobs] = carry_s;
 }
 
+// A literal run of K5_HUGE bytes or more (incompressible input: the whole chunk
+// can be ONE run) is not counted by the wave of k5 that owns its match: k4_compact
+// puts it on a list while it copies the record (the record holds the run's
+// start) and k5b_long_literals counts it, 16 KiB per workgroup, which
+// adds to the histogram k5 has written.  (A run of a whole 1 MiB chunk took one
+// wave 15 us per MiB; measured on random bytes K5 was a third of the total.)
+#ifndef M4G_K5_HUGE
+#define M4G_K5_HUGE 8192
+#endif
+constexpr uint32_t K5_HUGE = M4G_K5_HUGE;
+constexpr uint32_t K5B_SEG = 16384; // bytes per k5b work item
+constexpr int K5B_THREADS = 256;
+struct LongRun {
+  uint32_t job, start, count, pad;
+};
+
 // One wave per (job, sub-block): copy the block's true records (stitch part,
 // then the kept speculative part) to their place in the job's Match list.
 constexpr int K4_THREADS = 256;
 __global__ __launch_bounds__(K4_THREADS) void k4_compact(
     const Rec *__restrict__ rs, const Rec *__restrict__ st, const Job *__restrict__ jobs,
     const BlockDesc *__restrict__ desc, const uint64_t *__restrict__ out_off,
-    uint32_t *__restrict__ out /* 3 words per match */, uint64_t out_cap, int njobs, SpecLayout L) {
+    uint32_t *__restrict__ out /* 3 words per match */, uint64_t out_cap, int njobs, SpecLayout L,
+    LongRun *__restrict__ long_runs /* nullable */, uint32_t *__restrict__ n_long_runs, uint32_t long_cap) {
   const uint64_t t = (uint64_t)blockIdx.x * (K4_THREADS / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const uint32_t job = (uint32_t)(t / L.kmax), k = (uint32_t)(t % L.kmax);
@@ -1088,6 +1105,10 @@ __global__ __launch_bounds__(K4_THREADS) void k4_compact(
     dst[0] = v.x;
     dst[1] = v.y;
     dst[2] = v.z;
+    if (v.x >= K5_HUGE && long_runs) {
+      const uint32_t s = atomicAdd(n_long_runs, 1u);
+      if (s < long_cap) long_runs[s] = LongRun{job, v.w & ~kRecFlushBit, v.x, 0};
+    }
   }
 }
 
@@ -1356,7 +1377,7 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
         }
       }
     }
-    unsigned long long lm = __ballot(longrun);
+    unsigned long long lm = __ballot(longrun && un < K5_HUGE); // longer ones: k5b_long_literals
     while (lm) {
       int l = __builtin_ctzll(lm);
       lm &= lm - 1;
@@ -1373,6 +1394,54 @@ __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
   }
   for (int k = tid; k < 704; k += K5_THREADS) h[256 + k] = cmd[k];
   if (tid < 64) h[960 + tid] = dst[tid];
+}
+
+// Literal runs set aside by k5_histograms.  Work item id = run * segs_per_run +
+// segment (segs_per_run covers the longest possible run); a fixed grid strides
+// over the items, so no host round trip is needed to size the launch.
+__global__ __launch_bounds__(K5B_THREADS) void k5b_long_literals(
+    const uint8_t *__restrict__ src_base, const Job *__restrict__ jobs,
+    const LongRun *__restrict__ long_runs, const uint32_t *__restrict__ n_long_runs,
+    uint32_t long_cap, uint32_t segs_per_run, const uint64_t *__restrict__ out_off, uint64_t out_cap,
+    uint32_t *__restrict__ histos) {
+  __shared__ uint32_t lit[K5B_THREADS / 64][256];
+  const int tid = threadIdx.x, wid = tid >> 6;
+  const uint32_t nruns = min(*n_long_runs, long_cap);
+  const uint64_t items = (uint64_t)nruns * segs_per_run;
+  for (uint64_t id = blockIdx.x; id < items; id += gridDim.x) {
+    const LongRun R = long_runs[id / segs_per_run];
+    const uint32_t seg = (uint32_t)(id % segs_per_run);
+    if ((uint64_t)seg * K5B_SEG >= R.count) continue; // uniform for the workgroup
+    if (out_off[R.job + 1] > out_cap) continue;        // truncated list: k5 reports no histogram
+    for (int k = tid; k < (K5B_THREADS / 64) * 256; k += K5B_THREADS) (&lit[0][0])[k] = 0;
+    __syncthreads();
+    const uint8_t *p = src_base + jobs[R.job].src_off + R.start + (size_t)seg * K5B_SEG;
+    const uint32_t n = min(K5B_SEG, R.count - seg * K5B_SEG);
+    uint32_t *mylit = lit[wid];
+    // the run starts at an arbitrary byte: head up to 16-byte alignment, body, tail
+    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)p & 15)) & 15));
+    if ((uint32_t)tid < head) atomicAdd(&mylit[p[tid]], 1u);
+    const uint32_t body = (n - head) / 16;
+    const uint4 *q = reinterpret_cast<const uint4 *>(p + head);
+    for (uint32_t k = tid; k < body; k += K5B_THREADS) {
+      const uint4 v = q[k];
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) atomicAdd(&mylit[(w[a] >> (8 * b)) & 0xFF], 1u);
+    }
+    const uint32_t done = head + body * 16;
+    if ((uint32_t)tid < n - done) atomicAdd(&mylit[p[done + tid]], 1u);
+    __syncthreads();
+    uint32_t *h = histos + (size_t)R.job * 1024;
+    for (int k = tid; k < 256; k += K5B_THREADS) {
+      uint32_t c = 0;
+      for (int w = 0; w < K5B_THREADS / 64; w++) c += lit[w][k];
+      if (c) atomicAdd(&h[k], c);
+    }
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------

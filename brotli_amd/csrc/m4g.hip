@@ -264,13 +264,15 @@ int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint3
 
 // K4 for jobs already through launch_find: offsets, then the records.
 int launch_compact(const SpecWork &w, const Job *d_jobs, const uint32_t *d_counts, int njobs,
-                   uint64_t *d_out_off, m4g_match *d_out, size_t out_cap, hipStream_t st) {
+                   uint64_t *d_out_off, m4g_match *d_out, size_t out_cap, hipStream_t st,
+                   LongRun *d_long_runs = nullptr, uint32_t *d_n_long = nullptr, uint32_t long_cap = 0) {
   hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, d_counts, d_out_off, njobs);
   HIP_TRY(hipGetLastError());
   const uint64_t waves = (uint64_t)njobs * w.L.kmax;
   const unsigned g4 = (unsigned)((waves + (K4_THREADS / 64) - 1) / (K4_THREADS / 64));
   hipLaunchKernelGGL(k4_compact, dim3(g4), dim3(K4_THREADS), 0, st, w.rs, w.st, d_jobs, w.desc,
-                     d_out_off, reinterpret_cast<uint32_t *>(d_out), (uint64_t)out_cap, njobs, w.L);
+                     d_out_off, reinterpret_cast<uint32_t *>(d_out), (uint64_t)out_cap, njobs, w.L,
+                     d_long_runs, d_n_long, long_cap);
   HIP_TRY(hipGetLastError());
   return M4G_OK;
 }
@@ -341,6 +343,8 @@ struct m4g_batch {
   uint32_t *d_counts = nullptr;
   uint32_t *d_errors = nullptr;
   Job *d_jobs = nullptr;
+  LongRun *d_long_runs = nullptr; // literal runs >= K5_HUGE set aside by K5 for k5b_long_literals
+  uint32_t long_cap = 0;
   std::vector<uint64_t> last_off; // chunk_off of the jobs currently in d_jobs
   bool timing = false, ran = false;
   hipEvent_t ev[5] = {};
@@ -355,6 +359,7 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->d_counts);
   (void)hipFree(b->d_errors);
   (void)hipFree(b->d_jobs);
+  (void)hipFree(b->d_long_runs);
   for (auto &e : b->ev)
     if (e) (void)hipEventDestroy(e);
   delete b;
@@ -389,7 +394,10 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 4096)) != hipSuccess ||
       (e = hipMalloc(&b->d_counts, max_chunks * 4)) != hipSuccess ||
       (e = hipMalloc(&b->d_errors, 64)) != hipSuccess ||
-      (e = hipMalloc(&b->d_jobs, max_chunks * sizeof(Job))) != hipSuccess) {
+      (e = hipMalloc(&b->d_jobs, max_chunks * sizeof(Job))) != hipSuccess ||
+      (e = hipMalloc(&b->d_long_runs, (b->long_cap = (uint32_t)std::min<size_t>(
+                                           max_chunks * (max_chunk_bytes / K5_HUGE + 1), 1u << 28)) *
+                                          sizeof(LongRun))) != hipSuccess) {
     std::string msg = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
     m4g_batch_destroy(b);
     return fail(M4G_ERR_NO_MEMORY, msg);
@@ -468,7 +476,9 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
                        b->d_errors, st, b->timing ? b->ev[1] : nullptr);
   if (rc) return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
-  if ((rc = launch_compact(b->w, b->d_jobs, b->d_counts, njobs, d_out_off, d_out, out_cap, st)))
+  uint32_t *n_long = b->d_errors + 8; // zeroed with d_errors above
+  if ((rc = launch_compact(b->w, b->d_jobs, b->d_counts, njobs, d_out_off, d_out, out_cap, st,
+                           d_histos ? b->d_long_runs : nullptr, n_long, b->long_cap)))
     return rc;
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
 
@@ -485,6 +495,12 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
                          reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
                          (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
                          static_cast<CodeRec *>(nullptr));
+    HIP_TRY(hipGetLastError());
+    // the literal runs K4 set aside (none on compressible input: the grid finds an empty list)
+    const uint32_t segs = (uint32_t)((b->max_chunk_bytes + K5B_SEG - 1) / K5B_SEG);
+    hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, st, d_src, b->d_jobs,
+                       b->d_long_runs, n_long, b->long_cap, segs, d_out_off, (uint64_t)out_cap,
+                       reinterpret_cast<uint32_t *>(d_histos));
     HIP_TRY(hipGetLastError());
   }
   if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));

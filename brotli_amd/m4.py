@@ -87,7 +87,8 @@ def lib():
         L.m4g_batch_destroy.argtypes = [vp]
         L.m4g_batch_destroy.restype = None
         L.m4g_batch_run_device.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp]
-        L.m4g_batch_run_device_codes.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp, vp]
+        if hasattr(L, "m4g_batch_run_device_codes"):  # absent only in older experiment builds (M4G_LIB)
+            L.m4g_batch_run_device_codes.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp, vp]
         L.m4g_find_matches_batch.argtypes = [ctypes.POINTER(Params), vp, vp, sz, vp, ctypes.c_int,
                                              vp, vp, sz, vp]
         L.m4g_find_matches_batch.restype = ctypes.c_int64

@@ -304,3 +304,30 @@ def test_k1_uses_the_exchange_kernel_on_this_device():
     L = m4.lib()
     v = L.m4g_debug_k1_variant(0)
     assert v == (0 if os.environ.get("M4G_K1_SORT") else 1), v
+
+
+def test_histograms_of_long_literal_runs():
+    """Literal runs around and above the size from which they are counted by the
+    side kernel (k5b_long_literals, 8192 bytes) at odd offsets and lengths, several
+    per chunk, next to chunks without any: histograms must equal encoder.go:50-55."""
+    rng = np.random.default_rng(99)
+    rep = synth.text(300, 5)
+    chunks = []
+    for lens in ([8191, 8192, 8193], [16384 + 5, 3, 40000], [70001], [100], [8192 * 3 + 1, 8200]):
+        b = bytearray(b"x")
+        for n in lens:
+            b += bytes(rng.integers(0, 256, n, dtype=np.uint8)) + rep + rep
+        chunks.append(bytes(b))
+    chunks.append(synth.text(50000, 6))
+    blob = b"".join(chunks)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in chunks])]).astype(np.uint64)
+    out, out_off, histos = m4.find_matches_batch(blob, off, (0,), True, **PARAMS_G)
+    n_long = 0
+    for c, chunk in enumerate(chunks):
+        ref = OracleM4(**PARAMS_G).FindMatches(chunk)
+        assert same(out[int(out_off[c]):int(out_off[c + 1])], ref), f"chunk {c}"
+        n_long += int((np.asarray(ref).reshape(-1, 3)[:, 0] >= 8192).sum())
+        lit, cmd, dist, _, _ = histograms(chunk, ref)
+        assert (histos[c, :256] == lit).all(), f"chunk {c}: literal histogram"
+        assert (histos[c, 256:960] == cmd).all() and (histos[c, 960:] == dist).all(), f"chunk {c}"
+    assert n_long >= 8  # the case really exercises the side kernel
