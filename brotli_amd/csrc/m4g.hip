@@ -155,6 +155,16 @@ void spec_free(SpecWork &w) {
 
 constexpr int kDefaultSubBlock = 1024;
 
+// Lanes a single streaming call is spread over at least (spec_alloc's min_lanes).
+// One call is one job, so K3a's time is the serial walk of ONE sub-block per lane with nothing to
+// hide its memory round trips behind: the smaller the sub-block the better, down to 64 bytes
+// (measured per call, 64 KiB / 256 KiB / 1 MiB blocks: 512 lanes 344 / 1000 / 2285 us,
+// 16384 lanes 272 / 456 / 1222 us; 32-byte sub-blocks lose again: 412 us at 64 KiB).
+#ifndef M4G_STREAM_LANES
+#define M4G_STREAM_LANES 16384
+#endif
+constexpr size_t kStreamLanes = M4G_STREAM_LANES;
+
 int sub_block_size() {
   const char *e = std::getenv("M4G_SUB_BLOCK");
   int v = e ? std::atoi(e) : kDefaultSubBlock;
@@ -164,7 +174,7 @@ int sub_block_size() {
 // Layout for jobs of at most max_bytes buffer positions to parse.
 // min_lanes > 0 (one job per launch: the streaming handle): sub-blocks small enough that the job
 // spreads over at least that many lanes -- a 64 KiB block parsed by 64 lanes of 1 KiB each is one
-// wave walking 64 epochs in a row (1.4 ms per call); in 128-byte sub-blocks it takes 0.37 ms.
+// wave walking 64 epochs in a row (1.4 ms per call); in 128-byte sub-blocks it takes 0.37 ms, in 64-byte ones 0.27.
 int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, size_t min_lanes = 0) {
   spec_free(w);
   w.L.sub_block = sub_block_size();
@@ -1074,7 +1084,7 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   if (rc) return rc;
   if (c->w_bytes < n) {
     size_t nb = std::max(n, (size_t)1 << 16);
-    if ((rc = spec_alloc(c->w, p, 1, nb, 512))) return rc;
+    if ((rc = spec_alloc(c->w, p, 1, nb, kStreamLanes))) return rc;
     c->w_bytes = nb;
   }
   if (c->out_cap < need) {
