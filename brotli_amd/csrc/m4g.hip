@@ -937,6 +937,7 @@ struct m4g_ctx {
   uint32_t *d_counts = nullptr; // [0] count, [1] errors
   Job *d_job = nullptr;
   m4g_match *h_recs = nullptr; // pinned staging
+  size_t guess_recs = 0;       // records fetched together with the count (previous call's count + 25 %)
   // block-parallel mode (m4g_find_matches_blocks)
   SpecWork wb;                  // parse workspace for wb_jobs blocks of wb_bytes
   size_t wb_jobs = 0, wb_bytes = 0;
@@ -1118,18 +1119,26 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
   if (rc) return rc;
   if ((rc = launch_compact(c->w, c->d_job, c->d_counts, 1, c->d_out_off, c->d_out, c->out_cap, c->st)))
     return rc;
+  // The match count is only known on the device.  To get count and records in ONE round trip the
+  // records are fetched on a guess (the previous call's count + 25 %: consecutive blocks of a stream
+  // are alike); only a call that produced more pays a second copy.
+  const size_t guess = std::min(std::min(c->out_cap, out_cap), c->guess_recs);
   HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->st));
+  if (guess)
+    HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_out, guess * sizeof(m4g_match), hipMemcpyDeviceToHost, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
   c->hist_len += (int64_t)n;
   if (c->h_counts[1] & 1u) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
   if (c->h_counts[1] & 2u) return fail(M4G_ERR_HIP, "internal: parse slot overflow");
   const uint32_t cnt = c->h_counts[0];
   if (cnt > c->out_cap || cnt > out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
-  if (cnt) {
-    HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_out, (size_t)cnt * sizeof(m4g_match), hipMemcpyDeviceToHost, c->st));
+  if (cnt > guess) {
+    HIP_TRY(hipMemcpyAsync(c->h_recs + guess, c->d_out + guess, ((size_t)cnt - guess) * sizeof(m4g_match),
+                           hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
-    std::memcpy(out, c->h_recs, (size_t)cnt * sizeof(m4g_match));
   }
+  if (cnt) std::memcpy(out, c->h_recs, (size_t)cnt * sizeof(m4g_match));
+  c->guess_recs = (size_t)cnt + cnt / 4 + 64;
   return (int64_t)cnt;
 }
 
