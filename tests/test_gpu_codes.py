@@ -101,3 +101,53 @@ def test_codes_need_histograms():
     d_c = torch.empty(2 * 1026, dtype=torch.int32, device=dev)
     with pytest.raises(m4.M4GError):
         plan.run(d_src, np.array([0, 4096], dtype=np.uint64), d_out, d_off, None, d_codes=d_c)
+
+
+def test_device_api_with_an_output_that_is_too_small():
+    """m4g_batch_run_device contract (include/m4g.h): when the total exceeds
+    out_cap nothing is written past out_cap, d_out_off still holds the true
+    offsets, chunks whose lists fit are complete (matches, histograms, codes)
+    and a chunk whose list is cut reports an all-zero histogram -- also when
+    its literals are counted by the side kernel (a chunk of random bytes)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    chunks = [synth.text(n, 21), bytes(rng.integers(0, 256, n, dtype=np.uint8)), synth.text(n, 22),
+              bytes(rng.integers(0, 256, n, dtype=np.uint8)),
+              # cut below: its long literal run is listed for the side kernel, which must skip it
+              bytes(rng.integers(0, 256, 20000, dtype=np.uint8)) + synth.text(n - 20000, 23)]
+    host = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy()
+    off = np.arange(len(chunks) + 1, dtype=np.uint64) * n
+    refs = [np.asarray(OracleM4(**PARAMS_G).FindMatches(c), dtype=np.uint32).reshape(-1, 3) for c in chunks]
+    true_off = np.concatenate([[0], np.cumsum([len(r) for r in refs])])
+    # cut inside chunk 4: chunks 0..3 fit, chunk 4 does not
+    cap = int(true_off[4]) + 10
+    assert cap < true_off[5] and refs[4][0, 0] >= 8192
+    d_src = torch.from_numpy(host).to(dev)
+    plan = m4.BatchPlan(len(chunks), n, 0, **PARAMS_G)
+    d_out = torch.full((3 * cap + 300,), -1, dtype=torch.int32, device=dev)
+    d_off = torch.empty(len(chunks) + 1, dtype=torch.int64, device=dev)
+    d_h = torch.full((len(chunks) * 1024,), -1, dtype=torch.int32, device=dev)
+    d_c = torch.full((2 * cap + 200,), -1, dtype=torch.int32, device=dev)
+    # the tensors are larger than `cap` records on purpose: the guard words behind must stay untouched
+    rc = m4.lib().m4g_batch_run_device_codes(plan._h, d_src.data_ptr(), off.ctypes.data, len(chunks),
+                                             d_out.data_ptr(), d_off.data_ptr(), cap, d_h.data_ptr(),
+                                             d_c.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (d_off.cpu().numpy() == true_off).all()
+    out = d_out.cpu().numpy().view(np.uint32)
+    assert (out[3 * cap:] == 0xFFFFFFFF).all(), "records written past out_cap"
+    codes = d_c.cpu().numpy()
+    assert (codes[2 * cap:] == -1).all(), "codes written past out_cap"
+    h = d_h.cpu().numpy().view(np.uint32).reshape(-1, 1024)
+    out = out[:3 * cap].reshape(-1, 3)
+    cv = codes[:2 * cap].view(CODE_DTYPE)
+    for c in range(4):
+        a, b = int(true_off[c]), int(true_off[c + 1])
+        assert (out[a:b] == refs[c]).all(), f"chunk {c}"
+        lit, cmd, dist = _check_chunk(chunks[c], refs[c], cv[a:b], f"chunk {c}")
+        assert (h[c, :256] == lit).all() and (h[c, 256:960] == cmd).all() and (h[c, 960:] == dist).all()
+    assert (out[int(true_off[4]):cap] == refs[4][:10]).all()
+    assert (h[4] == 0).all(), "a truncated chunk reports no histogram"
