@@ -224,8 +224,11 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
           const uint32_t lo = v[j].x & mask_lo, hi = v[j].y & mask_hi;
           const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
           const uint32_t pos = sb + rel;
+          // the last 7 positions of a block are never inserted (m4.go:112).  blk_end is the end of
+          // the block the tile starts in; a tile can also hold the end of the call's LAST block when
+          // that one is shorter than a tile (every other block is longer than a tile)
           const bool in = rel < lim && (h >> part_bits) == q &&
-                          !(STREAM && pos + 7 >= blk_end && pos < blk_end);
+                          !(STREAM && ((pos + 7 >= blk_end && pos < blk_end) || pos + 7 >= st_xend));
           // check bits of the first 4 bytes (never 0: that value marks table
           // entries whose bytes are not known); cb >= 1 (launch_k1)
           const uint32_t ck = max(1u, (v[j].x * 0x9E3779B1u) >> (32 - cb));

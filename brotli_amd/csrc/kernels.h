@@ -387,8 +387,9 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
         const uint32_t lo = v[w].x & mask_lo, hi = v[w].y & mask_hi;
         const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
         const uint32_t pos = sb + rel;
+        // (blk_end: block the tile starts in; st_xend: a last block shorter than a tile, k1_xchg.h)
         const bool in = pos < end && (h >> part_bits) == q &&
-                        !(STREAM && pos + 7 >= blk_end && pos < blk_end);
+                        !(STREAM && ((pos + 7 >= blk_end && pos < blk_end) || pos + 7 >= st_xend));
         // check bits of the first 4 bytes (top bits of a multiplicative hash)
         // (never 0: that value marks table entries whose bytes are not known)
         const uint32_t ck = cb ? max(1u, (v[w].x * 0x9E3779B1u) >> (32 - cb)) : 0u;
@@ -691,14 +692,6 @@ __device__ __forceinline__ uint64_t k3_wave_of_block(uint32_t b, uint32_t nblock
 #endif
 constexpr int32_t K3_EXT_LIMIT = M4G_K3_EXT_LIMIT;
 
-// desc.out_off written by k3b, read by k3c
-constexpr uint32_t kStitchUnsynced = 0;   // whole block parsed from E[k-1], no common flush: ST + Tout hold the result
-constexpr uint32_t kStitchSynced = 1;     // joined the speculative records at keep_from
-constexpr uint32_t kStitchIncomplete = 2; // given up (entry state or this parse aborted): k3c parses the block
-// bits 8..: number of following blocks the stitch of block k went on into (k3b's chase): the status then
-// speaks about blocks k .. k+extra together, all records are in ST[k], keep_from belongs to block k+extra
-constexpr uint32_t K3_MAX_CHASE = 63;
-
 __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     const uint8_t *__restrict__ src_base, uint64_t src_total,
     const uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, Rec *__restrict__ rs,
@@ -793,32 +786,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
     return;
   }
   T.error &= kStateErrRange;
-  const int32_t len = (int32_t)J.len;
-  uint32_t keep = 0, extra = 0; // extra: blocks after k this stitch went on into
   GlobalMem M{src, chain};
-  bool ok = false, gave_up = false;
-  for (;;) {
-    const uint32_t b = k + extra;
-    const int32_t be = block_end(g, (int32_t)b);
-    const int32_t len_eff = (int64_t)be + K3_EXT_LIMIT < (int64_t)len ? be + K3_EXT_LIMIT : len;
-    const ParseState Eb = E[t + extra];
-    const uint32_t n_spec = (Eb.error & kStateAborted) ? 0u : min(desc[t + extra].n_spec, L.slot);
-    ok = stitch_block(M, len_eff, P, g, (int32_t)b, rs + (t + extra) * L.slot, n_spec, Eb, T, sink, keep);
-    gave_up = len_eff < len && (T.error & kStateTouchedEnd);
-    // A pending match that reaches past the block end leaves nothing to compare
-    // with yet: go on into the next block (no records so far, so the slot
-    // cannot overflow) until the match ends and the parse can join a speculative
-    // one.  A block left with nothing pending, or with records, ends the stitch.
-    if (ok || gave_up || sink.n != 0 || T.m0.end == 0 || T.i < be || b + 1 >= (uint32_t)g.nblocks ||
-        extra >= K3_MAX_CHASE)
-      break;
-    extra++;
-  }
-  d.n_stitch = sink.n;
-  d.keep_from = keep; // of block k + extra
-  d.out_off = (gave_up ? kStitchIncomplete : (ok ? kStitchSynced : kStitchUnsynced)) | (extra << 8);
+  if (stitch_chase(M, (int32_t)J.len, P, g, k, rs + t * L.slot, L.slot, E + t, desc + t, K3_EXT_LIMIT, T, sink, d))
+    Tout[t] = T;
   desc[t] = d;
-  if (!ok && !gave_up) Tout[t] = T;
   if (sink.n > L.slot) atomicOr(errors, 2u);
 }
 
@@ -954,20 +925,16 @@ __global__ __launch_bounds__(64) void k3c_validate(
       // differs from the state the speculative parse assumed only in next_emit
       // and in the repeat distance.  If no backward extension of the speculative
       // parse ran into its assumed next_emit (kStateHitLo) and the repeat probe
-      // with T's distance fails (4-byte compare) at every position before the
-      // first speculative record ends, the true parse IS the speculative one:
-      // same records (the first one starts its literals at T.next_emit), same
-      // end state.
-      bool fast = T.m0.end == 0 && T.i == bb && T.next_emit <= bb &&
-                  !(Ek.error & (kStateAborted | kStateHitLo | kStateErrRange));
-      int32_t first_end = be; // positions below it are probed with T's distance
-      if (fast && n_spec) first_end = min(be, rec_end(rs[t * L.slot]));
+      // with T's distance fails (4-byte compare) at every position up to the one
+      // where the speculative parse found its first match (m4_spec.h,
+      // fast_probe_limit), the true parse IS the speculative one: same records
+      // (the first one starts its literals at T.next_emit), same end state.
+      bool fast = fast_entry_ok(T, Ek, bb);
       if (fast && T.have_prev) {
+        const int32_t limit = fast_probe_limit(Ek, be); // positions below it are probed with T's distance
         bool hit = false;
-        for (int32_t i = bb + lane; i < first_end; i += 64) {
-          const int32_t p = i + 1, c = p - (int32_t)T.prev_dist;
-          if (c < 0 || p + 4 > len || ld32(src + c) == ld32(src + p)) hit = true;
-        }
+        for (int32_t i = bb + lane; i < limit; i += 64)
+          if (fast_probe_hits(src, len, i, T.prev_dist)) hit = true;
         if (__ballot(hit)) fast = false;
       }
       if (fast) {

@@ -54,7 +54,12 @@ struct ParseState {
   uint32_t prev_dist; // e.Dst[len-1].Distance, valid iff have_prev
   uint32_t have_prev; // len(e.Dst) > 0
   uint32_t error;     // kStateErrRange | diagnostic flags of the speculative parse (below)
+  int32_t first_i;    // loop position at which m0 first became non-empty since state_init (-1: not yet).
+                      // Up to and including it the parse probes with the ENTRY state's repeat distance
+                      // (m4.go:128-138 runs while nothing is pending); from there until the first emit a
+                      // match is pending, and the first emit replaces the distance (m4_spec.h, fast path)
 };
+static_assert(sizeof(ParseState) == 48, "ParseState is stored in arrays (E, Tout)");
 // ParseState.error bits.  Only kStateErrRange is an error (the Go code would
 // panic); the others tell the speculative sub-block parse (m4_spec.h) what a
 // result depended on.
@@ -213,6 +218,7 @@ M4G_HD void state_init(ParseState &S, int32_t start, uint32_t seed_prev_distance
   S.prev_dist = seed_prev_distance;
   S.have_prev = seed_prev_distance != 0;
   S.error = 0;
+  S.first_i = -1;
 }
 
 // Candidate evaluation from bytes that are already in registers: cf/cf2 = the
@@ -327,7 +333,10 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       AbsMatch m;
       if (cw == M.ld32(p) && match_at(M, len, p, c, S.next_emit + 1, m)) {
         if (m.end >= len) S.error |= kStateTouchedEnd;
-        if (m.end - m.start >= P.min_length) S.m0 = m;
+        if (m.end - m.start >= P.min_length) {
+          S.m0 = m;
+          if (S.first_i < 0) S.first_i = i;
+        }
       }
     }
 
@@ -414,6 +423,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     AbsMatch m2 = S.m1;
     S.m1 = S.m0;
     S.m0 = cur;
+    if (S.first_i < 0) S.first_i = i;
     if (m2.end != 0) {
       // G. m4.go:211-259
       if (S.m0.start < m2.end) {

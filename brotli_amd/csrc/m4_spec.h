@@ -125,4 +125,77 @@ M4G_HD bool stitch_block(const Mem &M, int32_t len, const ParseParams &P,
   return same_state;
 }
 
+// desc.out_off written by the stitch (k3b), read by the validation pass (k3c)
+constexpr uint32_t kStitchUnsynced = 0;   // whole block parsed from E[k-1], no common flush: ST + Tout hold the result
+constexpr uint32_t kStitchSynced = 1;     // joined the speculative records at keep_from
+constexpr uint32_t kStitchIncomplete = 2; // given up (entry state or this parse aborted): k3c parses the block
+// bits 8..: number of following blocks the stitch of block k went on into (the chase): the status then
+// speaks about blocks k .. k+extra together, all records are in ST[k], keep_from belongs to block k+extra
+constexpr uint32_t K3_MAX_CHASE = 63;
+
+// The stitch of block k >= 1 as k3b runs it: true parse from T (= E[k-1], the
+// state the block is ASSUMED to be entered in) until it joins the speculative
+// parse, following a pending match into the next blocks (the chase).
+// E_k / desc_k / rs_k point at block k's entries of the per-job arrays (block
+// k + x is entry x; slot records per block).  Fills d (status word in out_off);
+// returns true when T must be kept as Tout[k] (the block did not synchronise).
+template <class Mem, class Sink>
+M4G_HD bool stitch_chase(const Mem &M, int32_t len, const ParseParams &P, const SpecGeom &g,
+                         uint32_t k, const Rec *rs_k, uint32_t slot, const ParseState *E_k,
+                         const BlockDesc *desc_k, int32_t ext_limit, ParseState &T, Sink &sink,
+                         BlockDesc &d) {
+  uint32_t keep = 0, extra = 0; // extra: blocks after k this stitch went on into
+  bool ok = false, gave_up = false;
+  for (;;) {
+    const uint32_t b = k + extra;
+    const int32_t be = block_end(g, (int32_t)b);
+    const int32_t len_eff = (int64_t)be + ext_limit < (int64_t)len ? be + ext_limit : len;
+    const ParseState &Eb = E_k[extra];
+    uint32_t n_spec = 0;
+    if (!(Eb.error & kStateAborted)) n_spec = desc_k[extra].n_spec < slot ? desc_k[extra].n_spec : slot;
+    ok = stitch_block(M, len_eff, P, g, (int32_t)b, rs_k + (size_t)extra * slot, n_spec, Eb, T, sink, keep);
+    gave_up = len_eff < len && (T.error & kStateTouchedEnd);
+    // A pending match that reaches past the block end leaves nothing to compare
+    // with yet: go on into the next block (no records so far, so the slot
+    // cannot overflow) until the match ends and the parse can join a speculative
+    // one.  A block left with nothing pending, or with records, ends the stitch.
+    if (ok || gave_up || sink.n != 0 || T.m0.end == 0 || T.i < be || b + 1 >= (uint32_t)g.nblocks ||
+        extra >= K3_MAX_CHASE)
+      break;
+    extra++;
+  }
+  d.n_stitch = sink.n;
+  d.keep_from = keep; // of block k + extra
+  d.out_off = (gave_up ? kStitchIncomplete : (ok ? kStitchSynced : kStitchUnsynced)) | (extra << 8);
+  return !ok && !gave_up;
+}
+
+// ---- k3c fast path ----------------------------------------------------------
+// The true state T entering block k has nothing pending and stands at the block
+// start; the speculative parse of the block assumed (nothing pending, nothing
+// emitted, next_emit = block start).  The two differ only in next_emit and in
+// the repeat distance.  next_emit matters only as the lower bound of backward
+// extensions before the first emit (kStateHitLo records whether one reached the
+// assumed bound) and in the first record's literal count.  The repeat distance
+// matters only through the probe of m4.go:128-138, which runs at every loop
+// position while nothing is pending: positions block start .. E.first_i, the
+// position where the speculative parse found its first match, INCLUSIVE (the
+// probe precedes the search).  From there a match stays pending until the first
+// emit, and every emit replaces the distance.  (The first emitted record may
+// END at or before first_i: an older match trimmed to the start of a newer one,
+// m4.go:233-234 -- so the first record's end is NOT the bound.)
+M4G_HD bool fast_entry_ok(const ParseState &T, const ParseState &Ek, int32_t bb) {
+  return T.m0.end == 0 && T.i == bb && T.next_emit <= bb &&
+         !(Ek.error & (kStateAborted | kStateHitLo | kStateErrRange));
+}
+// positions [bb, limit) must be checked with T's distance
+M4G_HD int32_t fast_probe_limit(const ParseState &Ek, int32_t be) {
+  return Ek.first_i >= 0 && Ek.first_i + 1 < be ? Ek.first_i + 1 : be;
+}
+// would the probe at loop position i with distance prev_dist do anything (or fault)?
+M4G_HD bool fast_probe_hits(const uint8_t *src, int32_t len, int32_t i, uint32_t prev_dist) {
+  const int32_t p = i + 1, c = p - (int32_t)prev_dist;
+  return c < 0 || p + 4 > len || ld32(src + c) == ld32(src + p);
+}
+
 } // namespace m4g

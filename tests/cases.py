@@ -56,3 +56,43 @@ KATS = {
     "empty": [],
     "short3": [(3, 0, 0)],
 }
+
+
+# Parameters of fast_path_kat below.
+PARAMS_FAST_KAT = dict(HashLen=4)
+
+
+def fast_path_kat(P: int = 64, seed: int = 1) -> bytes:
+    """Input for the fast path of the validation pass (kernels.h k3c, m4_spec.h
+    fast_probe_limit) with sub-blocks of P bytes, parameters PARAMS_FAST_KAT.
+
+    Block 7 is entered by the TRUE parse with nothing pending and repeat distance
+    3P (block 5 holds a match at that distance, block 6 is unique bytes, so block
+    6 cannot synchronise).  In block 7 the parse that assumes "no repeat distance"
+    finds match A (u0..u9 v0..v5, source in block 1) at the position of u4 --
+    u0..u3 only have 4-byte decoy candidates, which m4.go:161 rejects -- extends it
+    back to u0, then finds the longer B (u4.. v19, source in block 0) at
+    A.End+2-HashLen and emits A trimmed to [u0,u4) (m4.go:233-234): the first
+    record ENDS at the position where A was FOUND.  The true parse probes there
+    (m4.go:128-138, i = position of u4) with distance 3P and hits the planted
+    "u5 u6 u7 u8" of block 4, so its result differs: a validation that checks the
+    probe only below the end of the first record accepts the wrong list."""
+    rng = np.random.default_rng(seed)
+    buf = bytearray(rng.integers(0, 0x80, 8 * P, dtype=np.uint8).tobytes())
+    u = bytes(0xA0 + t for t in range(10))
+    v = bytes(0xC0 + t for t in range(20))
+
+    def put(pos, s):
+        buf[pos:pos + len(s)] = s
+
+    put(0 * P + 8, b"\xE0" + u[4:] + v + b"\xE1")                    # SB
+    put(1 * P + 4, b"\xE2" + u + v[:6] + b"\xE3")                    # SA
+    o = 1 * P + 24
+    for t in range(4):                                               # decoys for u0..u3
+        put(o + 6 * t, bytes([0xE4 + t]) + u[t:t + 4] + bytes([0xE8 + t]))
+    c = 8 + 5                                                        # offset of u5 inside block 7
+    put(2 * P + 20, bytes(range(0xF0, 0xF8)))                        # source of the distance-3P match
+    put(4 * P + c - 1, b"\xEC" + u[5:9] + b"\xED")                   # planted repeat-probe target
+    put(5 * P + 20, bytes(range(0xF0, 0xF8)))                        # the match at distance 3P
+    put(7 * P + 8, u + v)                                            # block 7
+    return bytes(buf)

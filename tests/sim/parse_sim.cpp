@@ -124,5 +124,211 @@ int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, i
   if (!result.empty()) std::memcpy(out, result.data(), result.size() * sizeof(Rec));
   return (T.error & m4g::kStateErrRange) ? INT64_MIN : (int64_t)result.size();
 }
+
+// The whole K3 stage as the device runs it -- k3a (speculative parse with the
+// give-up rule), k3b (stitch_chase, shared with the kernel), k3c (validation:
+// scan of synchronised blocks, covered-block skip, fast path, serial re-stitch)
+// -- executed on the host, one "lane" after the other.  k3c's control flow is
+// restated here in scalar form (the kernel spreads it over a wave); its
+// decisions come from the same helpers (m4_spec.h: fast_entry_ok,
+// fast_probe_limit, fast_probe_hits, stitch_block).
+// legacy_limit != 0 reproduces the pre-round-2 bound of the fast path (probe
+// checks only below the END of the first speculative record) so that a test can
+// show an input on which that bound is wrong.
+// stats: [0] blocks, [1] fast-path blocks, [2] serially parsed, [3] skipped, [4] aborted spec lanes
+int64_t sim_find_matches_k3(const uint8_t *src, int32_t n, int max_distance, int min_length,
+                            int hash_len, int table_bits, int chain_length, int distance_bit_cost,
+                            uint32_t seed_prev, int32_t sub_block, int32_t ext_limit,
+                            int legacy_limit, uint32_t *out, int64_t out_cap, int64_t *stats) {
+  ParseParams P{max_distance, min_length, hash_len, chain_length, distance_bit_cost};
+  std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
+  build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
+  GlobalMem M{src, chain.data()};
+  const SpecGeom g = spec_geom(0, (uint32_t)n, sub_block);
+  const uint32_t K = (uint32_t)g.nblocks;
+  const uint32_t slot = (uint32_t)(sub_block / min_length + 18);
+  std::vector<Rec> rs((size_t)K * slot), st((size_t)K * slot);
+  std::vector<ParseState> E(K), Tout(K);
+  std::vector<BlockDesc> desc(K);
+  int64_t c_fast = 0, c_slow = 0, c_skip = 0, c_abort = 0;
+  uint32_t err = 0;
+  // ---- k3a ----
+  for (uint32_t k = 0; k < K; k++) {
+    const int32_t bb = block_begin(g, (int32_t)k), be = block_end(g, (int32_t)k);
+    const int32_t len_eff = (int64_t)be + ext_limit < (int64_t)n ? be + ext_limit : n;
+    RecSink sink{rs.data() + (size_t)k * slot, 0, slot};
+    ParseState S;
+    state_init(S, bb, k == 0 ? seed_prev : 0u);
+    parse_range<false>(M, len_eff, P, S, be, sink);
+    const bool aborted = len_eff < n && (S.error & kStateTouchedEnd);
+    if (aborted) {
+      S.error |= kStateAborted;
+      sink.n = 0;
+      c_abort++;
+    } else if (k == K - 1) {
+      parse_finish(n, P, S, sink);
+    }
+    E[k] = S;
+    desc[k] = BlockDesc{sink.n, 0, 0, 0};
+    if (sink.n > slot) err |= 2u;
+    if (k == 0 && !aborted && (S.error & kStateErrRange)) err |= 1u;
+  }
+  // ---- k3b ----
+  for (uint32_t k = 1; k < K; k++) {
+    RecSink sink{st.data() + (size_t)k * slot, 0, slot};
+    ParseState T = E[k - 1];
+    BlockDesc d = desc[k];
+    if (T.error & kStateAborted) {
+      d.n_stitch = 0;
+      d.keep_from = 0;
+      d.out_off = kStitchIncomplete;
+      desc[k] = d;
+      continue;
+    }
+    T.error &= kStateErrRange;
+    if (stitch_chase(M, n, P, g, k, rs.data() + (size_t)k * slot, slot, E.data() + k, desc.data() + k,
+                     ext_limit, T, sink, d))
+      Tout[k] = T;
+    desc[k] = d;
+    if (sink.n > slot) err |= 2u;
+  }
+  // ---- k3c ----
+  uint32_t off = 0, k = 1;
+  bool valid = true;
+  ParseState T;
+  state_init(T, g.start, seed_prev);
+  if (E[0].error & kStateAborted) {
+    valid = false;
+    k = 0;
+  } else {
+    off = desc[0].n_spec;
+    desc[0].out_off = 0;
+  }
+  while (k < K) {
+    if (valid) {
+      BlockDesc &d = desc[k];
+      if (d.out_off == kStitchSynced) { // plain sync
+        const uint32_t cnt = d.n_stitch + (d.n_spec - d.keep_from);
+        d.out_off = off;
+        off += cnt;
+        k++;
+        continue;
+      }
+      const uint32_t word = d.out_off, status = word & 0xFFu, extra = word >> 8;
+      const uint32_t ns = d.n_stitch, keep = d.keep_from;
+      if (status == kStitchIncomplete) {
+        valid = false;
+        T = E[k - 1];
+        T.error &= kStateErrRange;
+      } else {
+        uint32_t tail = 0;
+        for (uint32_t l = 0; l <= extra && k + l < K; l++) {
+          BlockDesc nd = desc[k + l];
+          const uint32_t nsp = nd.n_spec < slot ? nd.n_spec : slot;
+          nd.n_stitch = l == 0 ? ns : 0;
+          nd.keep_from = (status == kStitchSynced && l == extra) ? keep : nsp;
+          nd.out_off = off + (l == 0 ? 0 : ns);
+          if (status == kStitchSynced && l == extra) tail = nsp - (keep < nsp ? keep : nsp);
+          desc[k + l] = nd;
+        }
+        off += ns + tail;
+        if (status == kStitchUnsynced) {
+          valid = false;
+          T = Tout[k];
+        }
+        k += extra + 1;
+      }
+    } else {
+      const BlockDesc d = desc[k];
+      const ParseState Ek = E[k];
+      const int32_t bb = block_begin(g, (int32_t)k), be = block_end(g, (int32_t)k);
+      const uint32_t n_spec = d.n_spec < slot ? d.n_spec : slot;
+      if (T.i >= be && k + 1 < K) {
+        uint32_t covered_end = (uint32_t)((T.i - g.start) / g.sub_block);
+        if (covered_end > K - 1) covered_end = K - 1;
+        for (uint32_t kk = k; kk < covered_end; kk++) {
+          desc[kk].n_stitch = 0;
+          desc[kk].keep_from = desc[kk].n_spec < slot ? desc[kk].n_spec : slot;
+          desc[kk].out_off = off;
+        }
+        c_skip += covered_end - k;
+        k = covered_end;
+        continue;
+      }
+      bool fast = fast_entry_ok(T, Ek, bb);
+      if (fast && T.have_prev) {
+        int32_t limit = fast_probe_limit(Ek, be);
+        if (legacy_limit) {
+          limit = be;
+          if (n_spec) limit = rec_end(rs[(size_t)k * slot]) < be ? rec_end(rs[(size_t)k * slot]) : be;
+        }
+        for (int32_t i = bb; i < limit && fast; i++)
+          if (fast_probe_hits(src, n, i, T.prev_dist)) fast = false;
+      }
+      if (fast) {
+        if (n_spec) {
+          Rec &r = rs[(size_t)k * slot];
+          const uint32_t flag = r.lit_start & kRecFlushBit;
+          r.unmatched += (r.lit_start & ~kRecFlushBit) - (uint32_t)T.next_emit;
+          r.lit_start = (uint32_t)T.next_emit | flag;
+        }
+        desc[k].n_stitch = 0;
+        desc[k].keep_from = 0;
+        desc[k].out_off = off;
+        off += n_spec;
+        c_fast++;
+        const ParseState prevT = T;
+        T = Ek;
+        T.error = (Ek.error & kStateErrRange) | prevT.error;
+        if (n_spec == 0) {
+          T.next_emit = prevT.next_emit;
+          T.have_prev = prevT.have_prev;
+          T.prev_dist = prevT.prev_dist;
+        } else {
+          valid = true;
+        }
+        k++;
+        continue;
+      }
+      if (T.i >= be) c_skip++; else c_slow++;
+      RecSink sink{st.data() + (size_t)k * slot, 0, slot};
+      uint32_t keep = 0;
+      const bool ok = stitch_block(M, n, P, g, (int32_t)k, rs.data() + (size_t)k * slot, n_spec, Ek, T, sink, keep);
+      if (sink.n > slot) err |= 2u;
+      desc[k].n_stitch = sink.n;
+      desc[k].keep_from = keep;
+      desc[k].out_off = off;
+      off += sink.n + (n_spec - keep);
+      if (ok) valid = true;
+      k++;
+    }
+  }
+  if (T.error & kStateErrRange) err |= 1u;
+  // ---- k4: stitch part, then the kept speculative part, block by block ----
+  std::vector<Rec> result(off);
+  for (uint32_t b = 0; b < K; b++) {
+    const BlockDesc &d = desc[b];
+    const uint32_t nsp = d.n_spec < slot ? d.n_spec : slot;
+    const uint32_t ns = d.n_stitch < slot ? d.n_stitch : slot;
+    const uint32_t kf = d.keep_from < nsp ? d.keep_from : nsp;
+    const uint32_t nk = nsp - kf;
+    for (uint32_t r = 0; r < ns + nk; r++) {
+      if ((size_t)d.out_off + r >= result.size()) return -3; // layout broken
+      result[d.out_off + r] = r < ns ? st[(size_t)b * slot + r] : rs[(size_t)b * slot + d.keep_from + (r - ns)];
+    }
+  }
+  if (stats) {
+    stats[0] = K;
+    stats[1] = c_fast;
+    stats[2] = c_slow;
+    stats[3] = c_skip;
+    stats[4] = c_abort;
+  }
+  if (err & 2u) return -2;
+  for (auto &r : result) r.lit_start &= ~kRecFlushBit;
+  if ((int64_t)result.size() > out_cap) return -(int64_t)result.size() - 16;
+  if (!result.empty()) std::memcpy(out, result.data(), result.size() * sizeof(Rec));
+  return (err & 1u) ? INT64_MIN : (int64_t)result.size();
+}
 #endif
 }

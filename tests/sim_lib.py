@@ -47,3 +47,18 @@ def sim_spec(data, sub_block, seed=0, **kw):
                                     out.ctypes.data, len(out), stats.ctypes.data)
     assert r >= 0, r
     return out[:r, :3].copy(), stats
+
+
+def sim_k3(data, sub_block, ext_limit=4096, legacy_limit=False, seed=0, **kw):
+    """The whole K3 stage (k3a + k3b + k3c + k4) as the device runs it, on the host."""
+    a, buf, out, p = _args(data, **kw)
+    L = lib()
+    L.sim_find_matches_k3.restype = ctypes.c_int64
+    L.sim_find_matches_k3.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_int] * 6 + \
+        [ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+         ctypes.c_void_p]
+    stats = np.zeros(5, dtype=np.int64)
+    r = L.sim_find_matches_k3(buf.ctypes.data, len(a), *p, seed, sub_block, ext_limit,
+                              1 if legacy_limit else 0, out.ctypes.data, len(out), stats.ctypes.data)
+    assert r >= 0, r
+    return out[:r, :3].copy(), stats

@@ -107,3 +107,39 @@ def test_blocks_largest_window_slide():
     assert g.history_len() == o.history_len()
     tail = synth.text(100000, 3)
     assert same(g.find_matches(tail), o.FindMatches(tail))
+
+
+@pytest.mark.parametrize("tail", [1, 6, 7, 8, 100, 3000, 3841])
+@pytest.mark.parametrize("kw", [dict(MaxDistance=1 << 16, DistanceBitCost=66),
+                                dict(MaxDistance=1 << 16, ChainLength=4, HashLen=5, DistanceBitCost=66)],
+                         ids=["chain0", "chain4"])
+def test_blocks_short_last_block_leaves_the_sequential_tables(tail, kw):
+    """ADVICE r1 (k1_xchg.h): a last block shorter than a K1 tile.  Its last 7
+    positions must not be inserted (m4.go:112): the handle's table and chain
+    after the call are what block-after-block calls leave (table entries further
+    back than MaxDistance may be empty, include/m4g.h), and a follow-up call finds
+    the same matches."""
+    block = 20000
+    n = 5 * block + tail
+    data = synth.text(n + 30000, 500 + tail)
+    g, o = m4.M4(**kw), OracleM4(**kw)
+    got, off = g.find_matches_blocks(data[:n], block)
+    ref = oracle_blocks(o, data[:n], block)
+    for b, r in enumerate(ref):
+        assert same(got[int(off[b]):int(off[b + 1])], r), f"block {b}"
+    assert g.history_len() == o.history_len()
+    table, chain = g.dump_tables()
+    rt, rc = o.dump_table(), o.dump_chain()
+    if kw.get("ChainLength", 0) > 0:  # the reference keeps a chain only then
+        assert (chain == rc).all()
+    else:  # never-inserted positions (block tails) have no chain entry here either
+        h = g.history_len()
+        start = h - n
+        for b in range(5 + 1):
+            e = start + min(n, (b + 1) * block)
+            assert (chain[max(start, e - 7):e] == 0).all(), f"tail of block {b}"
+    diff = table != rt
+    W = kw["MaxDistance"]
+    assert ((table[diff] == 0) & (g.history_len() - rt[diff].astype(np.int64) > W)).all()
+    nxt = data[n:n + 30000]
+    assert same(g.find_matches(nxt), o.FindMatches(nxt))

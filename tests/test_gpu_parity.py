@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from brotli_amd import m4, synth
-from cases import KATS, PARAMS_D, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs
+from cases import (KATS, PARAMS_D, PARAMS_FAST_KAT, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs,
+                   fast_path_kat)
 from oracle_lib import OracleEncoder, OracleM4, brotli_decompress, histograms, replay
 
 pytestmark = pytest.mark.gpu
@@ -234,6 +235,20 @@ def test_batch_inputs_that_defeat_the_speculation():
             assert same(out[o[c]:o[c + 1]], ref), f"chunk {c} params {kw}"
             lit, cmd, dist, _, _ = histograms(chunk, ref)
             assert (h[c, :256] == lit).all() and (h[c, 256:960] == cmd).all() and (h[c, 960:] == dist).all()
+
+
+def test_fast_path_kat_gpu():
+    """cases.fast_path_kat (ADVICE r1, k3c fast path bound): through the streaming
+    handle, which cuts a small input into 64-byte sub-blocks, and as chunks of a
+    batch (1 KiB sub-blocks)."""
+    for seed in (1, 2, 3):
+        data = fast_path_kat(64, seed)
+        assert same(m4.M4(**PARAMS_FAST_KAT).find_matches(data), OracleM4(**PARAMS_FAST_KAT).FindMatches(data)), seed
+    chunks = [fast_path_kat(1024, seed) for seed in (1, 2, 3, 5)]
+    host = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy()
+    out, o, _ = _run_batch(host, len(chunks[0]), len(chunks), PARAMS_FAST_KAT)
+    for c, chunk in enumerate(chunks):
+        assert same(out[o[c]:o[c + 1]], OracleM4(**PARAMS_FAST_KAT).FindMatches(chunk)), f"chunk {c}"
 
 
 def test_full_size_chunks_properties():

@@ -9,11 +9,12 @@ import numpy as np
 import pytest
 
 from brotli_amd import synth
-from cases import KATS, PARAMS_D, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs
+from cases import (KATS, PARAMS_D, PARAMS_FAST_KAT, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs,
+                   fast_path_kat)
 from m4_py import M4Py
 from oracle_lib import (OracleEncoder, OracleM4, brotli_decompress, histograms, lib as olib,
                         replay)
-from sim_lib import sim, sim_spec
+from sim_lib import sim, sim_k3, sim_spec
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m4_matches.npz")
 
@@ -117,6 +118,63 @@ def test_speculation_synchronises_quickly_on_text():
     blocks, synced, walked = int(stats[0]), int(stats[1]), int(stats[2])
     assert synced == blocks - 1
     assert walked / (blocks - 1) < 64
+
+
+def _hard_for_speculation():
+    """Inputs on which sub-blocks do not synchronise through a common flush: the
+    validation pass (k3c) has to use its skip / fast path / serial re-stitch."""
+    rng = np.random.default_rng(5)
+    n = 40000
+    text = np.frombuffer(synth.text(n, 9), dtype=np.uint8)
+    rnd = rng.integers(0, 256, n, dtype=np.uint8)
+    para = [synth.text(int(rng.integers(200, 3000)), 50 + k) for k in range(6)]
+    return {
+        "random": rnd.tobytes(),
+        "zeros": bytes(n),
+        "period7": (b"abcdefg" * (n // 7 + 1))[:n],
+        "text_random": np.concatenate([text[:n // 2], rnd[:n // 2]]).tobytes(),
+        "random_text_zeros": np.concatenate([rnd[:n // 3], text[:n // 3], np.zeros(n // 3, np.uint8)]).tobytes(),
+        "far_repeats_in_noise": np.concatenate([rnd[:9000], rnd[:9000], rnd[1000:20000]]).tobytes(),
+        "paragraphs_repeated": b"".join(para[int(k)] for k in rng.integers(0, 6, 40)),
+        "lowent": rng.integers(0, 3, n, dtype=np.uint8).tobytes(),
+    }
+
+
+@pytest.mark.parametrize("kw", [PARAMS_G, dict(MaxDistance=1 << 16, ChainLength=4, HashLen=5, DistanceBitCost=66),
+                                dict(HashLen=4, ChainLength=1)], ids=ids)
+def test_k3_stage_model_vs_oracle(kw):
+    """The K3 stage as the device runs it (k3a give-up rule, k3b stitch + chase,
+    k3c scan / skip / fast path / re-stitch, k4 layout), modelled on the host from
+    the same headers (tests/sim/parse_sim.cpp), is bit-exact on inputs that
+    defeat the speculation, for several sub-block sizes and give-up distances."""
+    ins = dict(_hard_for_speculation())
+    ins["text_60k"] = synth.text(60000, 31)
+    paths = np.zeros(5, dtype=np.int64)
+    for name, data in ins.items():
+        ref = OracleM4(**kw).FindMatches(data)
+        for sub, ext in ((64, 64), (128, 4096), (1024, 4096), (1024, 256)):
+            got, stats = sim_k3(data, sub, ext_limit=ext, **kw)
+            assert same(got, ref), (name, sub, ext)
+            paths += stats
+    # the cases really reach every path of the validation pass
+    assert paths[1] > 0 and paths[2] > 0 and paths[3] > 0 and paths[4] > 0, paths
+
+
+@pytest.mark.parametrize("P", [64, 128, 1024])
+def test_fast_path_kat(P):
+    """ADVICE r1 (kernels.h k3c): the repeat probe must be checked up to and
+    including the position where the speculative parse FOUND its first match,
+    not only below the end of its first record.  cases.fast_path_kat builds the
+    input; the model run with the old bound returns a different list."""
+    for seed in (1, 2, 3):
+        data = fast_path_kat(P, seed)
+        ref = OracleM4(**PARAMS_FAST_KAT).FindMatches(data)
+        assert same(M4Py(**PARAMS_FAST_KAT).FindMatches([], data), ref)
+        got, stats = sim_k3(data, P, **PARAMS_FAST_KAT)
+        assert same(got, ref)
+        old, stats_old = sim_k3(data, P, legacy_limit=True, **PARAMS_FAST_KAT)
+        assert not same(old, ref), "the KAT no longer reaches the case it was built for"
+        assert stats_old[1] == stats[1] + 1  # the old bound took the fast path once more: on block 7
 
 
 def test_static_code_length_header_matches_reference_constant():
