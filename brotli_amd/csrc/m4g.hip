@@ -84,9 +84,11 @@ int check_device(int device) {
   return M4G_OK;
 }
 
-int k1_selftest();
-int k1_prepare() {
-  if (int rc = k1_selftest()) return rc;
+int k1_selftest(uint32_t *d_word);
+// d_word: a device word for the self-test's result; NULL = allocate one for the
+// duration (callers that must not allocate pass their own).
+int k1_prepare(uint32_t *d_word = nullptr) {
+  if (int rc = k1_selftest(d_word)) return rc;
   // > 64 KiB of dynamic LDS needs the attribute once per device.
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1_chain_build<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -106,26 +108,29 @@ int k1_prepare() {
 // K1 variant: the exchange kernel (k1_xchg.h), unless M4G_K1_SORT is set or the
 // device failed the ordering self-test (then the sorting kernel, kernels.h).
 std::atomic<int> g_xchg_order[64]; // per device: 0 = not tested, 1 = ordered, 2 = not ordered
+std::atomic<int> g_k1_force{-1};   // test hook (m4g_debug_set_k1_variant): -1 = automatic, 0 = sort, 1 = exchange
 bool k1_use_sort() {
+  const int f = g_k1_force.load();
+  if (f >= 0) return f == 0;
   static const bool forced = std::getenv("M4G_K1_SORT") != nullptr;
   if (forced) return true;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
   return g_xchg_order[dev].load() == 2;
 }
-int k1_selftest() {
+int k1_selftest(uint32_t *d_word) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || g_xchg_order[dev].load() != 0) return M4G_OK;
-  uint32_t *d = nullptr, h = 0;
-  HIP_TRY(hipMalloc(&d, 4));
+  uint32_t *d = d_word, h = 0;
+  if (!d) HIP_TRY(hipMalloc(&d, 4));
   hipError_t e = hipMemset(d, 0, 4);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(kx_order_selftest, dim3(8), dim3(256), 0, nullptr, d);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
+  if (!d_word) (void)hipFree(d);
   HIP_TRY(e);
   g_xchg_order[dev].store(h == 0 ? 1 : 2);
   if (h != 0)
@@ -314,6 +319,7 @@ extern "C" const char *m4g_strerror(int code) {
   case M4G_ERR_TOO_LARGE: return "input too large";
   case M4G_ERR_NO_MEMORY: return "out of memory";
   case M4G_ERR_REPEAT_RANGE: return "seeded repeat distance reaches before the history start";
+  case M4G_ERR_INTERNAL: return "internal error (kernel-side overflow); the output of the call is not valid";
   default: return code < 0 ? "output buffer too small (-(needed) returned)" : "ok";
   }
 }
@@ -344,17 +350,26 @@ extern "C" void m4g_host_free(void *p) {
 // ===========================================================================
 // batch plan
 // ===========================================================================
+// Device memory one pass of the batch pipeline (K1 -> K3 -> K4 -> K5) works in.
+// m4g_batch owns one (hipMalloc); the entry point that must not allocate points
+// one at its file-scope scratch array.
+struct BatchWork {
+  uint32_t *d_chain = nullptr;
+  SpecWork w;                     // RS / ST record slots, states, descriptors
+  uint32_t *d_counts = nullptr;   // matches per job
+  uint32_t *d_errors = nullptr;   // 16 words: [0] error bits, [4..7] k3c diagnostics, [8] long-run count
+  Job *d_jobs = nullptr;
+  LongRun *d_long_runs = nullptr; // literal runs >= K5_HUGE set aside by K4 for k5b_long_literals
+  uint32_t long_cap = 0;
+};
+
 struct m4g_batch {
   int device = 0;
   Params p{};
   size_t max_chunks = 0, max_chunk_bytes = 0;
-  uint32_t *d_chain = nullptr;
-  SpecWork w;
-  uint32_t *d_counts = nullptr;
-  uint32_t *d_errors = nullptr;
-  Job *d_jobs = nullptr;
-  LongRun *d_long_runs = nullptr; // literal runs >= K5_HUGE set aside by K5 for k5b_long_literals
-  uint32_t long_cap = 0;
+  BatchWork W;
+  Job *h_jobs = nullptr;          // page-locked image of d_jobs (the upload is asynchronous)
+  hipEvent_t ev_jobs = nullptr;   // the last upload of h_jobs has completed
   std::vector<uint64_t> last_off; // chunk_off of the jobs currently in d_jobs
   bool timing = false, ran = false;
   hipEvent_t ev[5] = {};
@@ -364,12 +379,15 @@ struct m4g_batch {
 extern "C" void m4g_batch_destroy(m4g_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  (void)hipFree(b->d_chain);
-  spec_free(b->w);
-  (void)hipFree(b->d_counts);
-  (void)hipFree(b->d_errors);
-  (void)hipFree(b->d_jobs);
-  (void)hipFree(b->d_long_runs);
+  if (b->ran) (void)hipStreamSynchronize(b->last_stream);
+  (void)hipFree(b->W.d_chain);
+  spec_free(b->W.w);
+  (void)hipFree(b->W.d_counts);
+  (void)hipFree(b->W.d_errors);
+  (void)hipFree(b->W.d_jobs);
+  (void)hipFree(b->W.d_long_runs);
+  if (b->h_jobs) (void)hipHostFree(b->h_jobs);
+  if (b->ev_jobs) (void)hipEventDestroy(b->ev_jobs);
   for (auto &e : b->ev)
     if (e) (void)hipEventDestroy(e);
   delete b;
@@ -396,18 +414,20 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   b->max_chunks = max_chunks;
   b->max_chunk_bytes = max_chunk_bytes;
   const size_t nbytes = max_chunks * max_chunk_bytes;
-  if ((rc = spec_alloc(b->w, p, max_chunks, max_chunk_bytes))) {
+  if ((rc = spec_alloc(b->W.w, p, max_chunks, max_chunk_bytes))) {
     m4g_batch_destroy(b);
     return rc;
   }
   hipError_t e;
-  if ((e = hipMalloc(&b->d_chain, (nbytes + 16 * max_chunks) * 4 + 4096)) != hipSuccess ||
-      (e = hipMalloc(&b->d_counts, max_chunks * 4)) != hipSuccess ||
-      (e = hipMalloc(&b->d_errors, 64)) != hipSuccess ||
-      (e = hipMalloc(&b->d_jobs, max_chunks * sizeof(Job))) != hipSuccess ||
-      (e = hipMalloc(&b->d_long_runs, (b->long_cap = (uint32_t)std::min<size_t>(
-                                           max_chunks * (max_chunk_bytes / K5_HUGE + 1), 1u << 28)) *
-                                          sizeof(LongRun))) != hipSuccess) {
+  if ((e = hipMalloc(&b->W.d_chain, (nbytes + 16 * max_chunks) * 4 + 4096)) != hipSuccess ||
+      (e = hipMalloc(&b->W.d_counts, max_chunks * 4)) != hipSuccess ||
+      (e = hipMalloc(&b->W.d_errors, 64)) != hipSuccess ||
+      (e = hipMalloc(&b->W.d_jobs, max_chunks * sizeof(Job))) != hipSuccess ||
+      (e = hipHostMalloc(reinterpret_cast<void **>(&b->h_jobs), max_chunks * sizeof(Job), hipHostMallocDefault)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&b->ev_jobs, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipMalloc(&b->W.d_long_runs, (b->W.long_cap = (uint32_t)std::min<size_t>(
+                                             max_chunks * (max_chunk_bytes / K5_HUGE + 1), 1u << 28)) *
+                                            sizeof(LongRun))) != hipSuccess) {
     std::string msg = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
     m4g_batch_destroy(b);
     return fail(M4G_ERR_NO_MEMORY, msg);
@@ -433,6 +453,70 @@ extern "C" int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src, const ui
                                     nullptr, hip_stream);
 }
 
+namespace {
+// Job descriptors of a batch of independent chunks (fresh state each): chunk c
+// is buffer [chunk_off[c], chunk_off[c+1]) of the source, its chain entries
+// start at a 16-entry aligned offset.
+int fill_batch_jobs(Job *jobs, const uint64_t *chunk_off, size_t nchunks, size_t max_chunk_bytes) {
+  uint64_t chain_off = 0;
+  for (size_t c = 0; c < nchunks; c++) {
+    if (chunk_off[c + 1] < chunk_off[c]) return fail(M4G_ERR_BAD_PARAM, "chunk_off not ascending");
+    const uint64_t n = chunk_off[c + 1] - chunk_off[c];
+    if (n > max_chunk_bytes) return fail(M4G_ERR_TOO_LARGE, "chunk larger than the plan's max_chunk_bytes");
+    Job J{};
+    J.src_off = chunk_off[c];
+    J.chain_off = chain_off;
+    J.len = (uint32_t)n;
+    jobs[c] = J;
+    chain_off += (n + 15) & ~(uint64_t)15;
+  }
+  return M4G_OK;
+}
+
+// K1 -> K3 -> K4 -> K5 for the njobs jobs already in W.d_jobs.  Everything is
+// enqueued on st; nothing here allocates or synchronises.  ev: five events
+// (stage boundaries) or null.
+int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, const uint8_t *d_src,
+                       uint64_t src_total, int njobs, m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
+                       m4g_histo *d_histos, m4g_code *d_codes, hipStream_t st, hipEvent_t *ev) {
+  HIP_TRY(hipMemsetAsync(W.d_errors, 0, 64, st));
+  if (ev) HIP_TRY(hipEventRecord(ev[0], st));
+  int rc = launch_find(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, W.w, W.d_counts,
+                       W.d_errors, st, ev ? ev[1] : nullptr);
+  if (rc) return rc;
+  if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+  uint32_t *n_long = W.d_errors + 8; // zeroed with d_errors above
+  if ((rc = launch_compact(W.w, W.d_jobs, W.d_counts, njobs, d_out_off, d_out, out_cap, st,
+                           d_histos ? W.d_long_runs : nullptr, n_long, W.long_cap)))
+    return rc;
+  if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+
+  if (d_histos) {
+    static_assert(sizeof(m4g_histo) == 1024 * 4, "m4g_histo layout");
+    static_assert(sizeof(m4g_code) == sizeof(CodeRec), "m4g_code layout");
+    if (d_codes)
+      hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
+                         reinterpret_cast<const uint32_t *>(d_out), W.d_jobs, d_out_off,
+                         (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
+                         reinterpret_cast<CodeRec *>(d_codes));
+    else
+      hipLaunchKernelGGL(k5_histograms<false>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
+                         reinterpret_cast<const uint32_t *>(d_out), W.d_jobs, d_out_off,
+                         (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
+                         static_cast<CodeRec *>(nullptr));
+    HIP_TRY(hipGetLastError());
+    // the literal runs K4 set aside (none on compressible input: the grid finds an empty list)
+    const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
+    hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, st, d_src, W.d_jobs,
+                       W.d_long_runs, n_long, W.long_cap, segs, d_out_off, (uint64_t)out_cap,
+                       reinterpret_cast<uint32_t *>(d_histos));
+    HIP_TRY(hipGetLastError());
+  }
+  if (ev) HIP_TRY(hipEventRecord(ev[4], st));
+  return M4G_OK;
+}
+} // namespace
+
 extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, const uint64_t *chunk_off,
                                           size_t nchunks, m4g_match *d_out, uint64_t *d_out_off,
                                           size_t out_cap, m4g_histo *d_histos, m4g_code *d_codes,
@@ -441,6 +525,8 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
     return fail(M4G_ERR_BAD_PARAM, "NULL argument");
   if (d_codes && !d_histos)
     return fail(M4G_ERR_BAD_PARAM, "d_codes needs d_histos (both come from the same pass)");
+  if (d_histos && b->p.min_length < 2) // a trimmed match could have Length 1: no copy length code (command.go:128)
+    return fail(M4G_ERR_BAD_PARAM, "histograms / codes need MinLength >= 2 (brotli has no copy length code for 1)");
   if (nchunks > b->max_chunks) return fail(M4G_ERR_TOO_LARGE, "nchunks above the plan's max_chunks");
   if (nchunks && !d_src) return fail(M4G_ERR_BAD_PARAM, "d_src is NULL");
   HIP_TRY(hipSetDevice(b->device));
@@ -457,73 +543,45 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
   bool same = b->last_off.size() == nchunks + 1 &&
               std::memcmp(b->last_off.data(), chunk_off, (nchunks + 1) * 8) == 0;
   if (!same) {
-    std::vector<Job> jobs(nchunks);
-    uint64_t chain_off = 0;
-    for (size_t c = 0; c < nchunks; c++) {
-      if (chunk_off[c + 1] < chunk_off[c]) return fail(M4G_ERR_BAD_PARAM, "chunk_off not ascending");
-      uint64_t n = chunk_off[c + 1] - chunk_off[c];
-      if (n > b->max_chunk_bytes)
-        return fail(M4G_ERR_TOO_LARGE, "chunk larger than the plan's max_chunk_bytes");
-      Job &J = jobs[c];
-      J.src_off = chunk_off[c];
-      J.chain_off = chain_off;
-      J.start = 0;
-      J.len = (uint32_t)n;
-      J.seed_prev = 0;
-      J.store_from = 0;
-      J.k1_flags = 0;
-      J.pad = 0;
-      chain_off += (n + 15) & ~(uint64_t)15;
-    }
-    // pageable source: the runtime stages it before returning, so `jobs` may die.
-    HIP_TRY(hipMemcpyAsync(b->d_jobs, jobs.data(), nchunks * sizeof(Job), hipMemcpyHostToDevice, st));
+    b->last_off.clear();
+    HIP_TRY(hipEventSynchronize(b->ev_jobs)); // an earlier upload may still be reading h_jobs
+    if (int rc = fill_batch_jobs(b->h_jobs, chunk_off, nchunks, b->max_chunk_bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(b->W.d_jobs, b->h_jobs, nchunks * sizeof(Job), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(b->ev_jobs, st));
     b->last_off.assign(chunk_off, chunk_off + nchunks + 1);
   }
 
-  HIP_TRY(hipMemsetAsync(b->d_errors, 0, 64, st));
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[0], st));
-  int rc = launch_find(b->p, d_src, chunk_off[nchunks], (uint32_t)b->max_chunk_bytes, b->d_chain, b->d_jobs, nullptr, njobs, b->w, b->d_counts,
-                       b->d_errors, st, b->timing ? b->ev[1] : nullptr);
+  int rc = run_batch_pipeline(b->p, b->W, (uint32_t)b->max_chunk_bytes, d_src, chunk_off[nchunks], njobs, d_out,
+                              d_out_off, out_cap, d_histos, d_codes, st, b->timing ? b->ev : nullptr);
   if (rc) return rc;
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[2], st));
-  uint32_t *n_long = b->d_errors + 8; // zeroed with d_errors above
-  if ((rc = launch_compact(b->w, b->d_jobs, b->d_counts, njobs, d_out_off, d_out, out_cap, st,
-                           d_histos ? b->d_long_runs : nullptr, n_long, b->long_cap)))
-    return rc;
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[3], st));
-
-  if (d_histos) {
-    static_assert(sizeof(m4g_histo) == 1024 * 4, "m4g_histo layout");
-    static_assert(sizeof(m4g_code) == sizeof(CodeRec), "m4g_code layout");
-    if (d_codes)
-      hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
-                         reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
-                         (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
-                         reinterpret_cast<CodeRec *>(d_codes));
-    else
-      hipLaunchKernelGGL(k5_histograms<false>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
-                         reinterpret_cast<const uint32_t *>(d_out), b->d_jobs, d_out_off,
-                         (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
-                         static_cast<CodeRec *>(nullptr));
-    HIP_TRY(hipGetLastError());
-    // the literal runs K4 set aside (none on compressible input: the grid finds an empty list)
-    const uint32_t segs = (uint32_t)((b->max_chunk_bytes + K5B_SEG - 1) / K5B_SEG);
-    hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, st, d_src, b->d_jobs,
-                       b->d_long_runs, n_long, b->long_cap, segs, d_out_off, (uint64_t)out_cap,
-                       reinterpret_cast<uint32_t *>(d_histos));
-    HIP_TRY(hipGetLastError());
-  }
-  if (b->timing) HIP_TRY(hipEventRecord(b->ev[4], st));
   if (std::getenv("M4G_TRACE_K3C")) { // diagnostics of the validation pass (forces a sync)
     uint32_t w[8] = {};
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(w, b->d_errors, sizeof(w), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(w, b->W.d_errors, sizeof(w), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "[m4g] k3c: %u scan steps, %u blocks accepted by the probe check, %u parsed serially, %u skipped (covered)\n",
                  w[4], w[5], w[6], w[7]);
   }
   b->ran = true;
   b->last_stream = st;
   return M4G_OK;
+}
+
+namespace {
+int status_from_error_word(uint32_t err) {
+  if (err & 2u) return fail(M4G_ERR_INTERNAL, "parse slot overflow: records were dropped, the output is not valid");
+  if (err & 1u) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+  return M4G_OK;
+}
+} // namespace
+
+extern "C" int m4g_batch_status(m4g_batch *b) {
+  if (!b) return fail(M4G_ERR_BAD_PARAM, "plan is NULL");
+  if (!b->ran) return M4G_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpy(&err, b->W.d_errors, 4, hipMemcpyDeviceToHost));
+  return status_from_error_word(err);
 }
 
 // Profiling aid (not part of include/m4g.h): runs K1 alone `reps` times on the
@@ -540,16 +598,34 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
   for (int r = 0; r < reps; r++)
     if (k1_use_sort())
       hipLaunchKernelGGL(k1_chain_build<false>, g1, dim3(K1_THREADS), k1_lds_bytes(pb), nullptr, d_src, src_total,
-                         b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
+                         b->W.d_chain, b->W.d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
     else
       hipLaunchKernelGGL(k1x_chain_build<false>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), nullptr, d_src, src_total,
-                         b->d_chain, b->d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
+                         b->W.d_chain, b->W.d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[1], nullptr));
   HIP_TRY(hipEventSynchronize(b->ev[1]));
   HIP_TRY(hipEventElapsedTime(ms_out, b->ev[0], b->ev[1]));
   *ms_out /= (float)reps;
   return M4G_OK;
+}
+
+// Test hooks (not part of include/m4g.h).  m4g_debug_set_k1_variant: -1 = automatic
+// choice, 0 = sorting kernel, 1 = exchange kernel, for every later launch of the
+// process.  m4g_debug_k1_run: K1 alone over the job list of the plan's last run,
+// chain entries written to the caller's buffer of m4g_debug_chain_words(b) words
+// (so a test can compare the two kernels' chain arrays on the device).
+extern "C" void m4g_debug_set_k1_variant(int v) { g_k1_force.store(v < 0 ? -1 : (v ? 1 : 0)); }
+extern "C" uint64_t m4g_debug_chain_words(m4g_batch *b) {
+  return b ? (uint64_t)(b->max_chunks * b->max_chunk_bytes + 16 * b->max_chunks) + 1024 : 0;
+}
+extern "C" int m4g_debug_k1_run(m4g_batch *b, const uint8_t *d_src, uint64_t src_total, int njobs,
+                                uint32_t *d_chain_out, void *hip_stream) {
+  if (!b || !d_chain_out || njobs <= 0 || (size_t)njobs > b->max_chunks || b->last_off.size() != (size_t)njobs + 1)
+    return fail(M4G_ERR_BAD_PARAM, "bad argument (run the plan on these chunks first)");
+  HIP_TRY(hipSetDevice(b->device));
+  return launch_k1(b->p, d_src, src_total, (uint32_t)b->max_chunk_bytes, d_chain_out, b->W.d_jobs, nullptr, njobs,
+                   static_cast<hipStream_t>(hip_stream), nullptr);
 }
 
 // Diagnostic (not part of include/m4g.h): which K1 kernel the device gets --
@@ -706,7 +782,7 @@ int64_t batch_one_device_pipelined(const m4g_params *params, const Params &p, co
     }
     PIPE_TRY(hipMemcpyAsync(P.h_out_off + k * (slice + 1), P.d_out_off + k * (slice + 1), (nc + 1) * 8,
                             hipMemcpyDeviceToHost, P.st_run));
-    PIPE_TRY(hipMemcpyAsync(P.h_err + k, P.plan->d_errors, 4, hipMemcpyDeviceToHost, P.st_run));
+    PIPE_TRY(hipMemcpyAsync(P.h_err + k, P.plan->W.d_errors, 4, hipMemcpyDeviceToHost, P.st_run));
     PIPE_TRY(hipEventRecord(P.ev_run[k], P.st_run));
   }
   tr.mark("enqueue");
@@ -727,8 +803,7 @@ int64_t batch_one_device_pipelined(const m4g_params *params, const Params &p, co
   }
   out_off[nchunks] = run;
   if (err)
-    result = err & 2u ? fail(M4G_ERR_HIP, "internal: parse slot overflow")
-                      : fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+    result = status_from_error_word(err);
   else if (run > out_cap)
     result = -(int64_t)run;
   else if (histos)
@@ -844,11 +919,10 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
     BATCH_TRY(hipSetDevice(P.device));
     BATCH_TRY(hipStreamSynchronize(P.st));
     uint32_t err = 0;
-    BATCH_TRY(hipMemcpy(&err, P.plan->d_errors, 4, hipMemcpyDeviceToHost));
+    BATCH_TRY(hipMemcpy(&err, P.plan->W.d_errors, 4, hipMemcpyDeviceToHost));
     if (err) {
       cleanup();
-      return err & 2u ? fail(M4G_ERR_HIP, "internal: parse slot overflow")
-                      : fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
+      return status_from_error_word(err);
     }
   }
   tr.mark("kernels done");
@@ -1128,8 +1202,7 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
     HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_out, guess * sizeof(m4g_match), hipMemcpyDeviceToHost, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
   c->hist_len += (int64_t)n;
-  if (c->h_counts[1] & 1u) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
-  if (c->h_counts[1] & 2u) return fail(M4G_ERR_HIP, "internal: parse slot overflow");
+  if (int rce = status_from_error_word(c->h_counts[1])) return rce;
   const uint32_t cnt = c->h_counts[0];
   if (cnt > c->out_cap || cnt > out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
   if (cnt > guess) {
@@ -1333,8 +1406,7 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
   }
   c->hist_len = (int64_t)new_len;
 
-  if (c->h_counts[1] & 1u) return fail(M4G_ERR_REPEAT_RANGE, "repeat distance out of range");
-  if (c->h_counts[1] & 2u) return fail(M4G_ERR_HIP, "internal: parse slot overflow");
+  if (int rce = status_from_error_word(c->h_counts[1])) return rce;
   const uint64_t cnt = off[nblocks];
   if (cnt > c->out_cap || cnt > out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
   if (cnt) {

@@ -38,6 +38,7 @@ EXPORTS = [
     "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_batch_run_device_codes",
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
+    "m4g_batch_status",
 ]
 
 _LIB = None
@@ -95,6 +96,7 @@ def lib():
         L.m4g_batch_last_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
         L.m4g_batch_set_timing.argtypes = [vp, ctypes.c_int]
         L.m4g_batch_set_timing.restype = None
+        L.m4g_batch_status.argtypes = [vp]
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
         L.m4g_host_free.argtypes = [vp]
@@ -329,6 +331,12 @@ class BatchPlan:
         ms = (ctypes.c_float * 4)()
         n = lib().m4g_batch_last_timings(self._h, ms, 4)
         return [float(ms[k]) for k in range(n)]
+
+    def status(self):
+        """Kernel-side outcome of the last run (m4g_batch_status): synchronises the
+        run's stream; raises M4GError if records were dropped or a repeat distance
+        was out of range."""
+        _check(lib().m4g_batch_status(self._h), "m4g_batch_status")
 
     def run(self, d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0,
             d_codes=None):

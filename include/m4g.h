@@ -83,8 +83,10 @@ enum {
   M4G_ERR_HIP = -1000003,       /* a HIP call failed; see m4g_last_error() */
   M4G_ERR_TOO_LARGE = -1000004, /* input beyond the limits stated below */
   M4G_ERR_NO_MEMORY = -1000005,
-  M4G_ERR_REPEAT_RANGE = -1000006 /* seeded repeat distance reaches before the
-                                     history start (the Go code would panic) */
+  M4G_ERR_REPEAT_RANGE = -1000006, /* seeded repeat distance reaches before the
+                                      history start (the Go code would panic) */
+  M4G_ERR_INTERNAL = -1000007      /* a kernel-side capacity check failed; the
+                                      output of that call is not valid */
 };
 /* Count-returning entry points use values >= -1000000 for "-(needed)". */
 
@@ -173,7 +175,11 @@ void m4g_batch_destroy(m4g_batch *b);
  *   d_out_off  : nchunks+1 uint64 (exclusive prefix sum of match counts).
  *   d_histos   : nullable; one m4g_histo per chunk.
  * If the total match count exceeds out_cap nothing is written past out_cap
- * and d_out_off still holds the true offsets (the caller can detect it). */
+ * and d_out_off still holds the true offsets (the caller can detect it); a
+ * chunk whose list was cut by out_cap gets an ALL-ZERO histogram (and no codes).
+ * d_histos needs MinLength >= 2 (M4G_ERR_BAD_PARAM otherwise): a trimmed match
+ * of Length 1 has no brotli copy length code (command.go:128-139; the Go code
+ * would index out of range). */
 int m4g_batch_run_device(m4g_batch *b, const uint8_t *d_src,
                          const uint64_t *chunk_off, size_t nchunks,
                          m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
@@ -202,6 +208,16 @@ int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
                                const int *devices, int ndevices, m4g_match *out,
                                uint64_t *out_off, size_t out_cap,
                                m4g_histo *histos);
+
+/* Kernel-side outcome of the plan's most recent m4g_batch_run_device[_codes]
+ * call.  Those calls only enqueue work and return before it runs, so conditions
+ * the kernels detect cannot come back through their return value: this call
+ * synchronises the stream of that run and returns M4G_OK, M4G_ERR_REPEAT_RANGE
+ * or M4G_ERR_INTERNAL (records were dropped; d_out / d_out_off of that run must
+ * not be used).  Has no counterpart in the reference (FindMatches cannot fail,
+ * m4.go:63); callers of the device-resident form check it once per batch, the
+ * host-memory forms check it themselves. */
+int m4g_batch_status(m4g_batch *b);
 
 /* Per-stage kernel time of the plan's most recent run, measured with HIP
  * events on the stream the kernels ran on.  Synchronises that stream.
