@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -582,6 +583,149 @@ extern "C" int m4g_batch_status(m4g_batch *b) {
   uint32_t err = 0;
   HIP_TRY(hipMemcpy(&err, b->W.d_errors, 4, hipMemcpyDeviceToHost));
   return status_from_error_word(err);
+}
+
+// ===========================================================================
+// The entry point that allocates nothing (include/m4g.h,
+// m4g_batch_run_device_noalloc): the batch pipeline with its workspace in a
+// file-scope device array instead of a plan's hipMalloc'ed buffers.
+// ===========================================================================
+namespace {
+constexpr size_t NA_MAX_CHUNKS = M4G_NOALLOC_MAX_CHUNKS;
+constexpr size_t NA_MAX_BYTES = M4G_NOALLOC_MAX_BYTES;
+constexpr size_t NA_MAX_BLOCKS = M4G_NOALLOC_MAX_BLOCKS;           // (chunk, sub-block) pairs
+constexpr size_t NA_MAX_RECS = NA_MAX_BLOCKS * (1024 / 4 + 18);    // records per RS / ST array
+constexpr size_t NA_LONG_CAP = NA_MAX_CHUNKS + NA_MAX_BYTES / K5_HUGE + 64;
+constexpr size_t na_align(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t NA_OFF_CHAIN = 0;
+constexpr size_t NA_OFF_RS = NA_OFF_CHAIN + na_align((NA_MAX_BYTES + 16 * NA_MAX_CHUNKS + 1024) * 4);
+constexpr size_t NA_OFF_ST = NA_OFF_RS + na_align(NA_MAX_RECS * sizeof(Rec));
+constexpr size_t NA_OFF_E = NA_OFF_ST + na_align(NA_MAX_RECS * sizeof(Rec));
+constexpr size_t NA_OFF_TOUT = NA_OFF_E + na_align(NA_MAX_BLOCKS * sizeof(ParseState));
+constexpr size_t NA_OFF_DESC = NA_OFF_TOUT + na_align(NA_MAX_BLOCKS * sizeof(ParseState));
+constexpr size_t NA_OFF_COUNTS = NA_OFF_DESC + na_align(NA_MAX_BLOCKS * sizeof(BlockDesc));
+constexpr size_t NA_OFF_ERRORS = NA_OFF_COUNTS + na_align(NA_MAX_CHUNKS * 4);
+constexpr size_t NA_OFF_JOBS = NA_OFF_ERRORS + na_align(64);
+constexpr size_t NA_OFF_LONG = NA_OFF_JOBS + na_align(NA_MAX_CHUNKS * sizeof(Job));
+constexpr size_t NA_SCRATCH_BYTES = NA_OFF_LONG + na_align(NA_LONG_CAP * sizeof(LongRun));
+static_assert(NA_SCRATCH_BYTES <= (size_t)16 << 20, "the scratch array is meant to stay modest");
+} // namespace
+
+// Every GPU the library runs on holds its own copy of this array, at its own
+// address, until the process ends.  In host code the NAME below is only a
+// stand-in for the symbol: the device address comes from hipGetSymbolAddress
+// (na_scratch_ptr), and host code uses that pointer and nothing else.
+static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
+
+namespace {
+struct NaOffsets {
+  uint64_t off[NA_MAX_CHUNKS + 1];
+};
+// Job descriptors from chunk offsets passed by value (no host-to-device copy, so
+// the entry point also works under stream capture): same layout rule as
+// fill_batch_jobs.
+__global__ __launch_bounds__(64) void kna_make_jobs(NaOffsets o, int n, Job *__restrict__ jobs) {
+  const int c = threadIdx.x;
+  if (c >= n) return;
+  uint64_t chain_off = 0;
+  for (int k = 0; k < c; k++) chain_off += (o.off[k + 1] - o.off[k] + 15) & ~(uint64_t)15;
+  Job J{};
+  J.src_off = o.off[c];
+  J.chain_off = chain_off;
+  J.len = (uint32_t)(o.off[c + 1] - o.off[c]);
+  jobs[c] = J;
+}
+
+std::atomic<unsigned char *> g_na_ptr[64]; // per device: address of its copy of `scratch`
+std::mutex g_na_mutex;
+
+// One-time set-up per device (the device is current): the array's address on
+// this device, the K1 ordering self-test (its result word lives in the scratch
+// too) and the kernels' LDS attributes.  Synchronises; later calls do not.
+int na_scratch_ptr(int device, unsigned char **out) {
+  if (device < 0 || device >= 64) return fail(M4G_ERR_NO_DEVICE, "device index out of range");
+  unsigned char *p = g_na_ptr[device].load();
+  if (!p) {
+    std::lock_guard<std::mutex> lock(g_na_mutex);
+    p = g_na_ptr[device].load();
+    if (!p) {
+      if (int rc = check_device(device)) return rc;
+      void *sym = nullptr;
+      HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+      if (!sym) return fail(M4G_ERR_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
+      if (int rc = k1_prepare(reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(sym) + NA_OFF_ERRORS))) return rc;
+      p = static_cast<unsigned char *>(sym);
+      g_na_ptr[device].store(p);
+    }
+  }
+  *out = p;
+  return M4G_OK;
+}
+} // namespace
+
+extern "C" int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uint8_t *d_src,
+                                            const uint64_t *chunk_off, size_t nchunks, m4g_match *d_out,
+                                            uint64_t *d_out_off, size_t out_cap, m4g_histo *d_histos,
+                                            void *hip_stream) {
+  Params p;
+  if (int rc = resolve_params(params, &p)) return rc;
+  if (!chunk_off || !d_out_off || (!d_out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (nchunks && !d_src) return fail(M4G_ERR_BAD_PARAM, "d_src is NULL");
+  if (d_histos && p.min_length < 2)
+    return fail(M4G_ERR_BAD_PARAM, "histograms need MinLength >= 2 (brotli has no copy length code for 1)");
+  if (nchunks > NA_MAX_CHUNKS)
+    return fail(M4G_ERR_TOO_LARGE, "m4g_batch_run_device_noalloc: more than M4G_NOALLOC_MAX_CHUNKS chunks");
+  size_t max_len = 1;
+  for (size_t c = 0; c < nchunks; c++) {
+    if (chunk_off[c + 1] < chunk_off[c]) return fail(M4G_ERR_BAD_PARAM, "chunk_off not ascending");
+    max_len = std::max<size_t>(max_len, chunk_off[c + 1] - chunk_off[c]);
+  }
+  if (nchunks && chunk_off[nchunks] - chunk_off[0] > NA_MAX_BYTES)
+    return fail(M4G_ERR_TOO_LARGE, "m4g_batch_run_device_noalloc: more than M4G_NOALLOC_MAX_BYTES bytes in one call");
+  // layout of the record slots for THIS call (the plan fixes it at create time)
+  SpecLayout L{};
+  L.sub_block = kDefaultSubBlock;
+  L.kmax = (uint32_t)((max_len + (size_t)L.sub_block - 1) / (size_t)L.sub_block);
+  L.slot = (uint32_t)((size_t)L.sub_block / (size_t)p.min_length + 18);
+  const size_t blocks = nchunks * L.kmax;
+  if (blocks > NA_MAX_BLOCKS || blocks * L.slot > NA_MAX_RECS)
+    return fail(M4G_ERR_TOO_LARGE,
+                "m4g_batch_run_device_noalloc: nchunks x ceil(largest chunk / 1024) exceeds M4G_NOALLOC_MAX_BLOCKS "
+                "(or MinLength < 4 needs more record slots than the scratch array holds)");
+  HIP_TRY(hipSetDevice(device));
+  unsigned char *base = nullptr;
+  if (int rc = na_scratch_ptr(device, &base)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (nchunks == 0) {
+    HIP_TRY(hipMemsetAsync(d_out_off, 0, sizeof(uint64_t), st));
+    return M4G_OK;
+  }
+  BatchWork W;
+  W.d_chain = reinterpret_cast<uint32_t *>(base + NA_OFF_CHAIN);
+  W.w.L = L;
+  W.w.blocks = blocks;
+  W.w.rs = reinterpret_cast<Rec *>(base + NA_OFF_RS);
+  W.w.st = reinterpret_cast<Rec *>(base + NA_OFF_ST);
+  W.w.E = reinterpret_cast<ParseState *>(base + NA_OFF_E);
+  W.w.Tout = reinterpret_cast<ParseState *>(base + NA_OFF_TOUT);
+  W.w.desc = reinterpret_cast<BlockDesc *>(base + NA_OFF_DESC);
+  W.d_counts = reinterpret_cast<uint32_t *>(base + NA_OFF_COUNTS);
+  W.d_errors = reinterpret_cast<uint32_t *>(base + NA_OFF_ERRORS);
+  W.d_jobs = reinterpret_cast<Job *>(base + NA_OFF_JOBS);
+  W.d_long_runs = reinterpret_cast<LongRun *>(base + NA_OFF_LONG);
+  W.long_cap = (uint32_t)NA_LONG_CAP;
+  // What must start at zero in the shared array: the error / counter words (the
+  // pipeline clears them itself) and nothing else -- every other word is written
+  // by the call before it is read (K1 writes the chain entry of every position
+  // the parse can reach: chunks start at position 0, and entries of the seven
+  // uninserted positions at a chunk's end are never read).
+  NaOffsets o;
+  for (size_t c = 0; c <= nchunks; c++) o.off[c] = chunk_off[c];
+  for (size_t c = nchunks + 1; c <= NA_MAX_CHUNKS; c++) o.off[c] = chunk_off[nchunks];
+  hipLaunchKernelGGL(kna_make_jobs, dim3(1), dim3(64), 0, st, o, (int)nchunks, W.d_jobs);
+  HIP_TRY(hipGetLastError());
+  return run_batch_pipeline(p, W, (uint32_t)max_len, d_src, chunk_off[nchunks], (int)nchunks, d_out, d_out_off, out_cap,
+                            d_histos, nullptr, st, nullptr);
 }
 
 // Profiling aid (not part of include/m4g.h): runs K1 alone `reps` times on the

@@ -38,7 +38,7 @@ EXPORTS = [
     "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_batch_run_device_codes",
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
-    "m4g_batch_status",
+    "m4g_batch_status", "m4g_batch_run_device_noalloc",
 ]
 
 _LIB = None
@@ -97,6 +97,7 @@ def lib():
         L.m4g_batch_set_timing.argtypes = [vp, ctypes.c_int]
         L.m4g_batch_set_timing.restype = None
         L.m4g_batch_status.argtypes = [vp]
+        L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
         L.m4g_host_free.argtypes = [vp]
@@ -363,6 +364,23 @@ class BatchPlan:
                                         d_histos.data_ptr() if d_histos is not None else None,
                                         stream if stream else None)
         _check(rc, "m4g_batch_run_device")
+
+
+def run_device_noalloc(d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0,
+                       device: int = 0, **m4_fields):
+    """m4g_batch_run_device_noalloc: BatchPlan.run without a plan -- the workspace
+    is a fixed array inside libm4g.so, the call allocates nothing (limits:
+    include/m4g.h M4G_NOALLOC_*)."""
+    p = _params(m4_fields.get("MaxDistance", 0), m4_fields.get("MinLength", 0),
+                m4_fields.get("HashLen", 0), m4_fields.get("TableBits", 0),
+                m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
+    off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+    out_cap = d_out.numel() * d_out.element_size() // 12
+    rc = lib().m4g_batch_run_device_noalloc(
+        ctypes.byref(p), device, d_src.data_ptr(), off.ctypes.data, off.size - 1, d_out.data_ptr(),
+        d_out_off.data_ptr(), out_cap, d_histos.data_ptr() if d_histos is not None else None,
+        stream if stream else None)
+    _check(rc, "m4g_batch_run_device_noalloc")
 
 
 class PinnedBuffer:

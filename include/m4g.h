@@ -227,6 +227,34 @@ int m4g_batch_last_timings(m4g_batch *b, float *ms, int cap);
 /* Enable (1) / disable (0) the event recording used by the call above. */
 void m4g_batch_set_timing(m4g_batch *b, int enabled);
 
+/* ---- the entry point that allocates nothing ------------------------------
+ * No counterpart in the reference.  It exists for callers that cannot call
+ * hipMalloc: code under HIP stream / graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same semantics and results as
+ * m4g_batch_run_device on a plan (fresh M4 state per chunk, optional
+ * histograms), but the workspace is a fixed array inside the library's code
+ * object (about 14 MiB, held by every GPU the library is used on until the
+ * process ends) instead of a plan, so the call makes no hipMalloc / hipFree and
+ * no host-to-device copy: it only enqueues kernels and one 64-byte memset on
+ * hip_stream and returns without synchronising.
+ * Limits (M4G_ERR_TOO_LARGE beyond them): */
+#define M4G_NOALLOC_MAX_CHUNKS 64        /* chunks per call */
+#define M4G_NOALLOC_MAX_BYTES (1u << 20) /* bytes per call, all chunks together */
+#define M4G_NOALLOC_MAX_BLOCKS 1088      /* nchunks x ceil(largest chunk / 1024) */
+/* (with MinLength < 4 a sub-block needs more record slots: the product above
+ * must then stay below 1088 x 274 / (1024 / MinLength + 18)).
+ * The FIRST call on a device does one-time set-up there (address of the array,
+ * a kernel self-test) and synchronises: make it before capturing.
+ * All calls on one GPU share that GPU's array, which keeps the last call's
+ * contents: two calls whose work overlaps in time on ONE GPU (two streams, two
+ * threads) race -- serialise them; calls on different GPUs are independent.
+ * Within the limits no kernel-side error can occur (no seeded repeat distance,
+ * record slots sized for the worst case), so there is no status call. */
+int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uint8_t *d_src,
+                                 const uint64_t *chunk_off, size_t nchunks,
+                                 m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
+                                 m4g_histo *d_histos, void *hip_stream);
+
 /* Host staging helpers for callers without a HIP binding (bench.py uses
  * torch tensors instead; the Go shim uses these): page-locked host memory.
  * Buffers handed to m4g_find_matches_batch / _blocks should come from here

@@ -1,0 +1,92 @@
+"""m4g_batch_run_device_noalloc (include/m4g.h): the batch pipeline with its
+workspace in a fixed device array inside libm4g.so -- no allocation by the
+call.  Its output must equal m4g_batch_run_device's on the same input, bit for
+bit, on two calls in a row (the second smaller, so whatever the first call left
+in the shared array is stale for it), and the limits must be enforced."""
+import numpy as np
+import pytest
+
+from brotli_amd import m4, synth
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(MaxDistance=1 << 20, DistanceBitCost=66)
+
+
+def _both(host, sizes, kw):
+    import torch
+    dev = torch.device("cuda:0")
+    n = len(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    d_src = torch.from_numpy(np.concatenate([host, np.zeros(64, np.uint8)])).to(dev)
+    cap = int(sum(s // 4 + 2 for s in sizes)) + 1
+    res = []
+    for which in ("plan", "noalloc"):
+        # poisoned outputs: every word the call must write is checked
+        d_out = torch.full((3 * cap,), -1, dtype=torch.int32, device=dev)
+        d_off = torch.full((n + 1,), -1, dtype=torch.int64, device=dev)
+        d_h = torch.full((max(n, 1) * 1024,), -1, dtype=torch.int32, device=dev)
+        if which == "plan":
+            plan = m4.BatchPlan(max(n, 1), max(max(sizes, default=1), 1), 0, **kw)
+            plan.run(d_src, off, d_out, d_off, d_h)
+            plan.status()
+        else:
+            m4.run_device_noalloc(d_src, off, d_out, d_off, d_h, **kw)
+        torch.cuda.synchronize()
+        o = d_off.cpu().numpy()
+        res.append((o, d_out.cpu().numpy()[:3 * int(o[-1])], d_h.cpu().numpy()[:n * 1024]))
+    return res
+
+
+def _check(host, sizes, kw=KW):
+    (o1, m1, h1), (o2, m2, h2) = _both(host, sizes, kw)
+    assert (o1 == o2).all(), "offsets differ"
+    assert o1[-1] > 0 or sum(sizes) == 0
+    assert (m1 == m2).all(), "match lists differ"
+    assert (h1 == h2).all(), "histograms differ"
+
+
+def test_no_alloc_equals_plan_two_calls_in_a_row():
+    rng = np.random.default_rng(3)
+    # first call: as large as the limits allow in one direction (one 1 MiB chunk)
+    big = np.frombuffer(synth.text(1 << 20, 71), dtype=np.uint8)
+    _check(big, [1 << 20])
+    # second call, smaller, different chunking: 5 ragged chunks incl. an empty one
+    sizes = [70001, 0, 12345, 8, 40000]
+    small = np.frombuffer(b"".join(synth.log(s, 80 + i) for i, s in enumerate(sizes)), dtype=np.uint8)
+    _check(small, sizes)
+    # third: many small chunks (64 x 16 KiB: the chunk-count limit), mixed kinds incl. noise and zeros
+    sizes = [16384] * 64
+    parts = []
+    for i in range(64):
+        if i % 4 == 0:
+            parts.append(rng.integers(0, 256, 16384, dtype=np.uint8).tobytes())
+        elif i % 4 == 1:
+            parts.append(bytes(16384))
+        else:
+            parts.append(synth.text(16384, 200 + i))
+    _check(np.frombuffer(b"".join(parts), dtype=np.uint8), sizes)
+    # and a chain-walking parameter set on a smaller input again
+    sizes = [30000, 30000]
+    _check(np.frombuffer(synth.text(60000, 5), dtype=np.uint8), sizes,
+           dict(MaxDistance=1 << 16, ChainLength=8, HashLen=5, DistanceBitCost=66))
+    # nothing to do
+    import torch
+    d_off = torch.full((1,), -1, dtype=torch.int64, device="cuda:0")
+    m4.run_device_noalloc(torch.zeros(64, dtype=torch.uint8, device="cuda:0"), np.zeros(1, np.uint64),
+                          torch.zeros(3, dtype=torch.int32, device="cuda:0"), d_off)
+    torch.cuda.synchronize()
+    assert int(d_off[0]) == 0
+
+
+def test_no_alloc_rejects_sizes_beyond_its_limits():
+    import torch
+    dev = torch.device("cuda:0")
+    d_src = torch.zeros((1 << 20) + 4096, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(3 * 1024, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(80, dtype=torch.int64, device=dev)
+    for off in (np.array([0, (1 << 20) + 1], dtype=np.uint64),                 # bytes
+                np.arange(66, dtype=np.uint64) * 100,                          # 65 chunks
+                np.concatenate([[0, 600000], 600000 + np.arange(1, 3) * 10]).astype(np.uint64)):  # 3 x 586 sub-blocks
+        with pytest.raises(m4.M4GError, match="noalloc"):
+            m4.run_device_noalloc(d_src, off, d_out, d_off, **KW)
