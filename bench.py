@@ -8,10 +8,16 @@ already resident in HBM.  Default workload = BASELINE.json configs[1]:
 4 GiB of synthetic Markov text in 4096 independent 1 MiB chunks, parameters
 G = M4{MaxDistance: 1<<20, DistanceBitCost: 66}.
 
-Multi-GPU (configs[2]): one process per GPU; every rank runs the same number
-of chunks (weak scaling, rank r owns chunk indices [r*C, (r+1)*C)); there is
-no data-path collective -- torch.distributed is used only for the barrier and
-the max-over-ranks of the elapsed time.
+Multi-GPU (configs[2]): one process per GPU.  `--scaling weak` (default): every
+rank runs --chunks chunks (rank r owns chunk indices [r*C, (r+1)*C)).
+`--scaling strong`: the SAME --chunks chunks are split over the ranks (config 3
+as written: "the same 4 GiB stream sharded across 2/4/8").  There is no
+data-path collective -- torch.distributed is used only for the barrier and the
+max-over-ranks of the elapsed time.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (child
+processes through torch.distributed.run, before this process touches a GPU) and
+fails if the node has fewer than N devices.
 
 Prints ONE JSON line on rank 0.
 """
@@ -20,17 +26,14 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import numpy as np
-import torch
-
-from brotli_amd import m4, synth
 
 PARAM_SETS = {
     # G = "M4 greedy", D = "deep-search stress"
@@ -40,37 +43,74 @@ PARAM_SETS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def shard_chunks(total_chunks_per_rank: int, rank: int) -> range:
-    """Weak scaling: rank r owns global chunk indices [r*C, (r+1)*C)."""
-    return range(rank * total_chunks_per_rank, (rank + 1) * total_chunks_per_rank)
+def shard_chunks(chunks: int, rank: int, world: int, scaling: str) -> range:
+    """Global chunk indices of `rank`.  weak: `chunks` per rank, rank r owns
+    [r*C, (r+1)*C).  strong: `chunks` in total, contiguous near-equal ranges."""
+    if scaling == "weak":
+        return range(rank * chunks, (rank + 1) * chunks)
+    lo = chunks * rank // world
+    hi = chunks * (rank + 1) // world
+    return range(lo, hi)
 
 
-def cpu_baseline(host: np.ndarray, chunk_bytes: int, kw: dict, nchunks: int, threads: int):
-    """Times the CPU oracle (C restatement of the reference's M4, not the Go
-    reference: Go is not installed) on a bounded sample of the same chunks."""
+def host_threads() -> int:
+    """Threads the CPU legs may use: the cores this process may run on, capped by
+    the box's OMP_NUM_THREADS share (a one-GPU box exports 16; os.cpu_count()
+    there shows the whole machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS")
+    if cap and cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_find_matches(host, chunk_bytes: int, kw: dict, chunks, threads: int):
+    """The CPU oracle (C restatement of the reference's M4; Go is not installed)
+    over `chunks` (local indices), one M4 per thread, Reset per chunk -- the
+    shape of the reference's benchmark() (brotli_test.go:651-676).  Returns
+    (seconds spent in FindMatches, {chunk: match list})."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle_lib import OracleM4
+    chunks = list(chunks)
 
     def work(t):
         o = OracleM4(**kw)
-        for c in range(t, nchunks, threads):
+        res = {}
+        for c in chunks[t::threads]:
             o.Reset()
-            o.FindMatches(host[c * chunk_bytes:(c + 1) * chunk_bytes])
-        return 0
+            res[c] = o.FindMatches(host[c * chunk_bytes:(c + 1) * chunk_bytes])
+        return res
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(work, range(threads)))
+        parts = list(ex.map(work, range(threads)))
     dt = time.perf_counter() - t0
-    return nchunks * chunk_bytes / dt / 1e9
+    out = {}
+    for p in parts:
+        out.update(p)
+    return dt, out
 
 
 def pmc_traffic(kernel: str, args, input_bytes: int):
     """HBM-side bytes per launch of `kernel` (GB), from the rocprofv3 --pmc passes
     committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be collected
     inside this process; tools/pmc_traffic.py turns the two passes into
-    bytes per input byte for one workload, scaled here to this launch).
-    None when no measurement for this workload is on file."""
+    bytes per input byte for one workload, scaled here to this launch).  A
+    stored measurement, not one of this run.  None when none is on file."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -82,12 +122,20 @@ def pmc_traffic(kernel: str, args, input_bytes: int):
     return None if per_byte is None else round(per_byte * input_bytes / 1e9, 3)
 
 
-def main():
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunks", type=int, default=4096, help="chunks per GPU")
+    ap.add_argument("--chunks", type=int, default=4096,
+                    help="chunks per GPU (weak scaling) or in total (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--chunk-bytes", type=int, default=1 << 20)
     ap.add_argument("--params", choices=sorted(PARAM_SETS), default="G")
     ap.add_argument("--kind", choices=["text", "log"], default="text")
@@ -95,17 +143,42 @@ def main():
     ap.add_argument("--codes", action="store_true",
                     help="also write the per-match command / distCache records (m4g_batch_run_device_codes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=2048)
-    ap.add_argument("--verify-chunks", type=int, default=8)
+    ap.add_argument("--verify-chunks", type=int, default=-1,
+                    help="chunks per rank compared with the oracle (-1 = every chunk)")
+    ap.add_argument("--cpu-1thread-chunks", type=int, default=384)
+    ap.add_argument("--encode-sample-chunks", type=int, default=48)
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--e2e-sample-chunks", type=int, default=512)
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # No launcher: start the ranks ourselves, before this process has made
+        # any GPU call (device_count() does not initialise the GPU on this image).
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
+            raise SystemExit(2)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
+    import numpy as np
+    import torch
+    from brotli_amd import m4, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -116,13 +189,17 @@ def main():
     torch.cuda.set_device(dev)
 
     kw = PARAM_SETS[args.params]
-    n, C = args.chunk_bytes, args.chunks
-    min_len = kw.get("MinLength", 0) or 4
+    n = args.chunk_bytes
+    mine = shard_chunks(args.chunks, rank, world, args.scaling)
+    C = len(mine)
+    total_chunks = args.chunks * world if args.scaling == "weak" else args.chunks
+    if C == 0:
+        raise SystemExit("fewer chunks than ranks")
 
     # ---- synthetic input, generated on the host, then resident in HBM ------
-    nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
+    nthreads = max(1, host_threads() // max(1, world))
     host = np.empty(n * C, dtype=np.uint8)
-    synth.fill(host, n, shard_chunks(C, rank).start, args.kind, nthreads)
+    synth.fill(host, n, mine.start, args.kind, nthreads)
     d_src = torch.empty(n * C + 64, dtype=torch.uint8, device=dev)
     piece = 256 << 20
     for o in range(0, host.size, piece):
@@ -157,13 +234,15 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel durations of the last step (HIP events on the launch stream);
-    # re-run untimed steps to average them without touching the timed region
+    plan.status()  # kernel-side errors of the device-resident API (records dropped, repeat range)
+    # per-kernel durations (HIP events recorded by the library on the launch
+    # stream): re-run untimed steps so the timed region is not touched
     reps = max(1, min(args.steps, 3))
     for _ in range(reps):
         step()
         stage_ms += np.array(plan.last_timings())
     stage_ms /= reps
+    plan.status()
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -174,33 +253,68 @@ def main():
     if total_matches > out_cap:
         raise SystemExit(f"output capacity too small: {total_matches} > {out_cap}")
 
-    # ---- parity gate on a sample (untimed) ---------------------------------
-    from oracle_lib import OracleEncoder, OracleM4, brotli_decompress, histograms
+    # ---- CPU leg + parity gate (untimed for the GPU) ------------------------
+    # The oracle runs over the chunks anyway for the CPU baseline; its Match
+    # lists are kept and compared, with the histograms, against the GPU output of
+    # EVERY one of them ("bit-exact Match lists vs oracle on every chunk").
+    from oracle_lib import OracleEncoder, brotli_decompress, histograms
+    nverify = C if args.verify_chunks < 0 else min(C, args.verify_chunks)
+    if args.no_cpu_baseline and args.verify_chunks < 0:
+        nverify = min(C, 8)
+    vchunks = [int(c) for c in np.unique(np.linspace(0, C - 1, num=nverify, dtype=int))] if nverify else []
+    threads = nthreads
+    cpu_dt, ref_lists = cpu_find_matches(host, n, kw, vchunks, threads)
     o = d_off.cpu().numpy()
-    verified = 0
-    stream_bytes = roundtrips = 0
-    for c in np.linspace(0, C - 1, num=min(args.verify_chunks, C), dtype=int):
+    got_all = d_out[:3 * total_matches].cpu().numpy().view(np.uint32).reshape(-1, 3)
+    hist_all = None if d_h is None else d_h.cpu().numpy().view(np.uint32).reshape(C, 1024)
+
+    def check(c):
         chunk = host[c * n:(c + 1) * n]
-        ref = OracleM4(**kw).FindMatches(chunk)
-        got = d_out[3 * int(o[c]):3 * int(o[c + 1])].cpu().numpy().view(np.uint32).reshape(-1, 3)
+        ref = ref_lists[c]
+        got = got_all[int(o[c]):int(o[c + 1])]
         if got.shape != ref.shape or not (got == ref).all():
-            raise SystemExit(f"PARITY FAILURE on chunk {c}")
-        if d_h is not None:
+            return f"PARITY FAILURE on local chunk {c} (rank {rank})"
+        if hist_all is not None:
             lit, cmd, dst, _, _ = histograms(chunk, ref)
-            h = d_h[c * 1024:(c + 1) * 1024].cpu().numpy().view(np.uint32)
+            h = hist_all[c]
             if not ((h[:256] == lit).all() and (h[256:960] == cmd).all() and (h[960:] == dst).all()):
-                raise SystemExit(f"HISTOGRAM PARITY FAILURE on chunk {c}")
-        # the reference's own criterion (brotli_test.go:626-649): the stream the
-        # restated Encoder builds from the GPU's matches decodes back to the input
-        stream = OracleEncoder().Encode(chunk, got, True)
-        stream_bytes += len(stream)
+                return f"HISTOGRAM PARITY FAILURE on local chunk {c} (rank {rank})"
+        return None
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(threads) as ex:
+        for msg in ex.map(check, vchunks):
+            if msg:
+                raise SystemExit(msg)
+    verified = len(vchunks)
+
+    # the reference's own criterion (brotli_test.go:626-649) on a sample: the
+    # stream the restated Encoder builds from the GPU's matches decodes back to
+    # the input; also times the CPU Encode a real pipeline would run after us
+    stream_bytes = roundtrips = 0
+    enc_s = 0.0
+    enc_chunks = [c for c in vchunks[::max(1, len(vchunks) // max(1, args.encode_sample_chunks))]][:args.encode_sample_chunks]
+    for c in enc_chunks:
+        chunk = host[c * n:(c + 1) * n]
+        got = got_all[int(o[c]):int(o[c + 1])]
+        enc = OracleEncoder()
+        t1 = time.perf_counter()
+        bs = enc.Encode(chunk, got, True)
+        enc_s += time.perf_counter() - t1
+        stream_bytes += len(bs)
         try:
-            if brotli_decompress(stream, n) != chunk.tobytes():
-                raise SystemExit(f"ROUND TRIP FAILURE on chunk {c}")
+            if brotli_decompress(bs, n) != chunk.tobytes():
+                raise SystemExit(f"ROUND TRIP FAILURE on local chunk {c} (rank {rank})")
             roundtrips += 1
         except RuntimeError:
             pass  # no libbrotlidec on this box: ratio only
-        verified += 1
+
+    if dist is not None:
+        v = torch.tensor([verified, roundtrips], dtype=torch.int64, device=dev)
+        dist.all_reduce(v)
+        verified_all, roundtrips_all = int(v[0]), int(v[1])
+    else:
+        verified_all, roundtrips_all = verified, roundtrips
 
     if rank != 0:
         if dist is not None:
@@ -208,7 +322,7 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    total_bytes = n * C * world
+    total_bytes = n * total_chunks
     value = total_bytes / (elapsed / args.steps) / 1e9
 
     # roofline of the dominant kernel: algorithmic bytes of one launch =
@@ -226,21 +340,23 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"{C} x {n} B independent chunks per GPU of synthetic Markov {args.kind}"
-                        f" ({C * n / 2**30:.2f} GiB/GPU), fresh M4 state per chunk",
+            "workload": f"{total_chunks} x {n} B independent chunks of synthetic Markov {args.kind}"
+                        f" ({total_chunks * n / 2**30:.2f} GiB over {world} GPU(s), {C} chunks on rank 0),"
+                        f" fresh M4 state per chunk",
             "params": args.params,
             "m4": kw,
             "histograms": d_h is not None,
             "per_match_codes": d_codes is not None,
             "matches_per_MiB": round(total_matches / (C * n / 2**20), 1),
-            "parity_checked_chunks": verified,
-            "roundtrip_checked_chunks": roundtrips,
-            "compression_ratio": round(verified * n / stream_bytes, 3) if stream_bytes else None,
+            "parity_checked_chunks": verified_all,
+            "parity_checked_of": total_chunks,
+            "roundtrip_checked_chunks": roundtrips_all,
+            "compression_ratio": round(len(enc_chunks) * n / stream_bytes, 3) if stream_bytes else None,
         },
         "stage_ms": {names[k]: round(float(stage_ms[k]), 3) for k in range(4)},
         "roofline": {
@@ -251,25 +367,41 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": pmc_traffic(names[dom], args, n * C),
+            "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc passes, not this run)",
             "algorithmic_bytes_per_launch": alg_bytes,
+            "whole_path_frac": round(alg_bytes / (float(stage_ms.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            if stage_ms.sum() > 0 else None,
         },
     }
     # rate of the measured HBM-side traffic (GB/s): how close the kernel's REAL bytes are to the peak
     tr = out["roofline"]["traffic"]
     out["roofline"]["traffic_rate"] = round(tr / (stage_ms[dom] * 1e-3), 1) if tr and stage_ms[dom] > 0 else None
-    if not args.no_cpu_baseline and world == 1:
-        threads = max(1, min(16, os.cpu_count() or 1))
-        sample = min(C, args.cpu_sample_chunks)
-        v = cpu_baseline(host, n, kw, sample, threads)
+    if not args.no_cpu_baseline and world == 1 and verified:
+        # one thread, on a bounded prefix of the same chunks
+        s1 = min(len(vchunks), args.cpu_1thread_chunks)
+        dt1, _ = cpu_find_matches(host, n, kw, vchunks[:s1], 1)
         out["cpu_baseline"] = {
-            "value": round(v, 4),
+            "value": round(verified * n / cpu_dt / 1e9, 4),
             "unit": "GB/s",
             "cores": threads,
             "kind": "port",
-            "sample": f"first {sample} chunks of the same workload ({sample * n / 2**20:.0f} MiB), "
-                      f"C restatement of the reference's M4 (oracle/m4_ref.c; Go is unavailable), "
-                      f"{threads} threads, one M4 per thread, Reset per chunk",
+            "value_1thread": round(s1 * n / dt1 / 1e9, 4),
+            "cpu": cpu_model(),
+            "host_cpus_visible": os.cpu_count(),
+            "sample": f"{verified} chunks of the same workload ({verified * n / 2**20:.0f} MiB), C restatement of the "
+                      f"reference's M4 (oracle/m4_ref.c; Go is unavailable), {threads} threads (this process's CPU "
+                      f"share: affinity capped by OMP_NUM_THREADS), one M4 per thread, Reset per chunk, FindMatches "
+                      f"only; value_1thread: the first {s1} of them on one thread",
         }
+        if enc_chunks and enc_s > 0:
+            out["cpu_encode"] = {
+                "s_per_GiB": round(enc_s / (len(enc_chunks) * n / 2**30), 3),
+                "value": round(len(enc_chunks) * n / enc_s / 1e9, 4),
+                "unit": "GB/s",
+                "cores": 1,
+                "sample": f"restated brotli.Encoder.Encode (oracle/encoder_ref.c) on {len(enc_chunks)} chunks, one "
+                          f"thread: the serial stage a V2 pipeline runs after match finding (SURVEY section 7)",
+            }
     if not args.no_end_to_end and world == 1:
         # PCIe-inclusive rate of the host-memory API on a bounded sample: wall
         # clock from the first H2D enqueue to the last D2H completion (SURVEY

@@ -12,15 +12,17 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, chunks_per_rank, q):
+def _worker(rank, world, port, chunks_per_rank, q, scaling="weak"):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
     from brotli_amd import synth
     from oracle_lib import OracleM4
-    own = bench.shard_chunks(chunks_per_rank, rank)
+    total = chunks_per_rank if scaling == "weak" else chunks_per_rank * world + 1  # strong: a ragged split
+    own = bench.shard_chunks(total, rank, world, scaling)
     n = 1 << 14
+    chunks_per_rank = len(own)
     host = np.empty(n * chunks_per_rank, dtype=np.uint8)
     synth.fill(host, n, own.start, "text", 2)
     # what each rank would produce for its shard (oracle stands in for the GPU here)
@@ -34,12 +36,16 @@ def _worker(rank, world, port, chunks_per_rank, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_shard_disjointly():
+import pytest
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_shard_disjointly(scaling):
     world, per = 2, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per, q, scaling)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
@@ -47,7 +53,7 @@ def test_two_ranks_shard_disjointly():
         p.join(60)
         assert p.exitcode == 0
     idx = [i for r in res for i in r[1]]
-    assert idx == list(range(world * per))          # disjoint, ordered cover
+    assert idx == list(range(world * per + (scaling == "strong")))  # disjoint, ordered cover of every chunk
     assert all(r[3] == float(world) for r in res)   # max over ranks reached everyone
     # chunk content depends on the global chunk index only
     sys.path[:0] = [ROOT]
@@ -55,3 +61,21 @@ def test_two_ranks_shard_disjointly():
     for r in res:
         assert synth.text(1 << 14, r[1][0])[:64] == r[4]
     assert all(c > 0 for r in res for c in r[2])
+
+
+def test_bench_gpus_n_refuses_a_node_with_fewer_devices():
+    """`python bench.py --gpus 8` without a launcher used to measure
+    one GPU silently.  It now starts the ranks itself, and exits non-zero before
+    anything else when the node has fewer devices than asked for (this container
+    has none)."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node really has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr, r.stderr
+    env["WORLD_SIZE"] = "4"  # a launcher that started a different number of ranks than --gpus says
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
