@@ -1,0 +1,196 @@
+// Package m4gpu is matchfinder.M4 on an AMD MI355X: a cgo binding of libm4g
+// (include/m4g.h) that implements matchfinder.MatchFinder
+// (matchfinder/matchfinder.go:23-30), so matchfinder.Writer, brotli.Encoder and
+// the flate encoders of andybalholm/brotli keep working unchanged.
+//
+// NOT COMPILED in the build image of this repository (it has no Go toolchain):
+// the same call sequences are exercised from C++ (include/m4g_matchfinder.hpp,
+// tests/sim/host_mirror_check.cpp) and from Python (brotli_amd/m4.py).
+//
+// Place this directory at matchfinder/m4gpu inside a checkout of the reference
+// and point the two cgo paths below at this repository's include/ and
+// brotli_amd/ (or install libm4g.so and m4g.h system-wide).
+package m4gpu
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../third_party/m4g/include
+#cgo LDFLAGS: -L${SRCDIR}/../../third_party/m4g/lib -lm4g -Wl,-rpath,${SRCDIR}/../../third_party/m4g/lib
+#include <stdlib.h>
+#include "m4g.h"
+*/
+import "C"
+
+import (
+	"runtime"
+	"unsafe"
+
+	"github.com/andybalholm/brotli/matchfinder"
+)
+
+// M4 has the exported fields of matchfinder.M4 (matchfinder/m4.go:15-43) plus
+// the HIP device to run on.  Zero fields take the reference's defaults
+// (m4.go:64-75).  Like matchfinder.M4 it must not be used by two goroutines at
+// once; distinct values are independent.
+type M4 struct {
+	MaxDistance, MinLength, HashLen, TableBits, ChainLength, DistanceBitCost int
+	Device                                                                 int
+
+	ctx *C.m4g_ctx
+	buf []C.m4g_match
+}
+
+var _ matchfinder.MatchFinder = (*M4)(nil)
+
+func fail(where string, rc C.int) {
+	panic("m4gpu: " + where + ": " + C.GoString(C.m4g_strerror(rc)) + ": " + C.GoString(C.m4g_last_error()))
+}
+
+func (q *M4) params() C.m4g_params {
+	return C.m4g_params{
+		max_distance: C.int32_t(q.MaxDistance), min_length: C.int32_t(q.MinLength),
+		hash_len: C.int32_t(q.HashLen), table_bits: C.int32_t(q.TableBits),
+		chain_length: C.int32_t(q.ChainLength), distance_bit_cost: C.int32_t(q.DistanceBitCost),
+	}
+}
+
+func (q *M4) minLength() int {
+	if q.MinLength == 0 {
+		return 4 // m4.go:67-69
+	}
+	return q.MinLength
+}
+
+func (q *M4) init() {
+	if q.ctx != nil {
+		return
+	}
+	p := q.params()
+	if rc := C.m4g_create(&p, C.int(q.Device), &q.ctx); rc != 0 {
+		fail("m4g_create", rc)
+	}
+	runtime.SetFinalizer(q, func(q *M4) { C.m4g_destroy(q.ctx) })
+}
+
+// Reset implements matchfinder.MatchFinder (m4.go:51-57).
+func (q *M4) Reset() {
+	if q.ctx != nil {
+		if rc := C.m4g_reset(q.ctx); rc != 0 {
+			fail("m4g_reset", rc)
+		}
+	}
+}
+
+// FindMatches implements matchfinder.MatchFinder (m4.go:63-283): same
+// streaming semantics (history, hash table and chain live on the device and
+// slide as in m4.go:82-99), same Match list.
+func (q *M4) FindMatches(dst []matchfinder.Match, src []byte) []matchfinder.Match {
+	q.init()
+	need := len(src)/q.minLength() + 2
+	if len(q.buf) < need {
+		q.buf = make([]C.m4g_match, need)
+	}
+	var seed C.uint32_t
+	if len(dst) > 0 { // m4.go:129-130 reads the caller's last Distance
+		seed = C.uint32_t(dst[len(dst)-1].Distance)
+	}
+	var p *C.uint8_t
+	if len(src) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&src[0])) // borrowed for the call only; the library copies it
+	}
+	n := C.m4g_find_matches(q.ctx, p, C.size_t(len(src)), seed, &q.buf[0], C.size_t(len(q.buf)))
+	if n < 0 {
+		fail("m4g_find_matches", C.int(n))
+	}
+	for _, m := range q.buf[:n] { // widen 3 x u32 to matchfinder.Match (3 x int)
+		dst = append(dst, matchfinder.Match{
+			Unmatched: int(m.unmatched), Length: int(m.length), Distance: int(m.distance)})
+	}
+	return dst
+}
+
+// FindMatchesBlocks returns what FindMatches(nil, block) returns for each of
+// the consecutive blockSize-byte blocks of src (the last may be shorter), all
+// computed in one launch; blockOff[b]:blockOff[b+1] delimits block b's list.
+// The handle ends in the state the block-by-block calls would leave.  This is
+// what a buffering variant of matchfinder.Writer.Write (matchfinder.go:59-79)
+// calls instead of one FindMatches per block (a 64 KiB call is latency bound).
+func (q *M4) FindMatchesBlocks(src []byte, blockSize int) (matches []matchfinder.Match, blockOff []uint64) {
+	q.init()
+	nblocks := (len(src) + blockSize - 1) / blockSize
+	need := 0
+	for b := 0; b < nblocks; b++ {
+		need += min(blockSize, len(src)-b*blockSize)/q.minLength() + 2
+	}
+	if len(q.buf) < need+1 {
+		q.buf = make([]C.m4g_match, need+1)
+	}
+	blockOff = make([]uint64, nblocks+1)
+	var p *C.uint8_t
+	if len(src) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&src[0]))
+	}
+	n := C.m4g_find_matches_blocks(q.ctx, p, C.size_t(len(src)), C.size_t(blockSize),
+		&q.buf[0], C.size_t(len(q.buf)), (*C.uint64_t)(unsafe.Pointer(&blockOff[0])))
+	if n < 0 {
+		fail("m4g_find_matches_blocks", C.int(n))
+	}
+	matches = make([]matchfinder.Match, n)
+	for i, m := range q.buf[:n] {
+		matches[i] = matchfinder.Match{Unmatched: int(m.unmatched), Length: int(m.length), Distance: int(m.distance)}
+	}
+	return
+}
+
+// Histograms are the three histograms pass 1 of brotli.Encoder.Encode builds
+// (encoder.go:33-35), as the GPU returns them per chunk.
+type Histograms struct {
+	Literal  [256]uint32
+	Command  [704]uint32
+	Distance [64]uint32
+}
+
+// Batch runs `AutoReset{&M4{...}}.FindMatches(nil, chunk)` (textencoder.go:46-53)
+// for every chunk data[chunkOff[c]:chunkOff[c+1]] on the given devices (chunk c
+// on devices[c % len(devices)], no inter-GPU traffic) and returns the Match
+// lists concatenated in chunk order with their offsets, plus (optionally) each
+// chunk's Encoder histograms.  data and the returned slices are ordinary Go
+// memory; for the 20+ GB/s path allocate them with m4g_host_alloc (see
+// INTEGRATION.md section 2).
+func (q *M4) Batch(data []byte, chunkOff []uint64, devices []int, wantHistos bool) (
+	matches []matchfinder.Match, outOff []uint64, histos []Histograms) {
+	nchunks := len(chunkOff) - 1
+	if nchunks <= 0 {
+		return nil, []uint64{0}, nil
+	}
+	need := 1
+	for c := 0; c < nchunks; c++ {
+		need += int(chunkOff[c+1]-chunkOff[c])/q.minLength() + 2
+	}
+	out := make([]C.m4g_match, need)
+	outOff = make([]uint64, nchunks+1)
+	devs := make([]C.int, len(devices))
+	for i, d := range devices {
+		devs[i] = C.int(d)
+	}
+	var hp *C.m4g_histo
+	if wantHistos {
+		histos = make([]Histograms, nchunks)
+		hp = (*C.m4g_histo)(unsafe.Pointer(&histos[0]))
+	}
+	p := q.params()
+	var dp *C.uint8_t
+	if len(data) > 0 {
+		dp = (*C.uint8_t)(unsafe.Pointer(&data[0]))
+	}
+	rc := C.m4g_find_matches_batch(&p, dp, (*C.uint64_t)(unsafe.Pointer(&chunkOff[0])), C.size_t(nchunks),
+		&devs[0], C.int(len(devs)), &out[0], (*C.uint64_t)(unsafe.Pointer(&outOff[0])), C.size_t(len(out)), hp)
+	if rc != 0 {
+		fail("m4g_find_matches_batch", C.int(rc))
+	}
+	matches = make([]matchfinder.Match, outOff[nchunks])
+	for i := range matches {
+		m := out[i]
+		matches[i] = matchfinder.Match{Unmatched: int(m.unmatched), Length: int(m.length), Distance: int(m.distance)}
+	}
+	return
+}

@@ -25,7 +25,8 @@ class HistoStruct(ctypes.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_ROOT, "oracle", "libm4oracle.so")
+        # M4G_ORACLE_SO: an instrumented build of the same sources (tools/oracle_coverage.py)
+        path = os.environ.get("M4G_ORACLE_SO") or os.path.join(_ROOT, "oracle", "libm4oracle.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run __graft_entry__.build() (or `make -C oracle`)")
         L = ctypes.CDLL(path)

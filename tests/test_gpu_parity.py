@@ -7,7 +7,7 @@ import pytest
 
 from brotli_amd import m4, synth
 from cases import (KATS, PARAMS_D, PARAMS_FAST_KAT, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs,
-                   fast_path_kat)
+                   fast_path_kat, hand_kats)
 from oracle_lib import OracleEncoder, OracleM4, brotli_decompress, histograms, replay
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +24,22 @@ def test_kats_streaming_api():
     for name, exp in KATS.items():
         got = m4.M4().find_matches(inputs[name])
         assert same(got, exp), name
+
+
+def test_hand_traced_queue_kats_gpu():
+    """cases.hand_kats: answers traced by hand through m4.go:187-259, through the
+    streaming handle and as one batch (all of them as chunks of one launch)."""
+    kats = hand_kats()
+    for name, (kw, data, exp, reaches) in kats.items():
+        assert same(m4.M4(**kw).find_matches(data), exp), (name, reaches)
+    for kw in (dict(), dict(ChainLength=1)):
+        sel = [(n, v) for n, v in kats.items() if v[0] == kw]
+        base = np.frombuffer(b"".join(v[1] for _, v in sel), dtype=np.uint8)
+        coff = np.cumsum([0] + [len(v[1]) for _, v in sel])
+        out, off, _ = m4.find_matches_batch(base, coff, **kw)
+        off = off.astype(np.int64)
+        for c, (n, v) in enumerate(sel):
+            assert same(out[off[c]:off[c + 1]], v[2]), n
 
 
 @pytest.mark.parametrize("kw", [PARAMS_G, PARAMS_D] + PARAMS_REF_TESTS + PARAMS_MISC,

@@ -10,7 +10,7 @@ import pytest
 
 from brotli_amd import synth
 from cases import (KATS, PARAMS_D, PARAMS_FAST_KAT, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs,
-                   fast_path_kat)
+                   fast_path_kat, hand_kats)
 from m4_py import M4Py
 from oracle_lib import (OracleEncoder, OracleM4, brotli_decompress, histograms, lib as olib,
                         replay)
@@ -37,6 +37,33 @@ def test_kats_surveyed_known_answers():
         assert same(M4Py().FindMatches([], ins[name]), exp), name
         # DistanceBitCost 66 gives the same result on these
         assert same(OracleM4(DistanceBitCost=66).FindMatches(ins[name]), exp), name
+
+
+def _bucket_collisions(data, hash_len=6, table_bits=17):
+    """distinct hash_len-byte windows that share a table bucket (m4.go:141)"""
+    seen, n = {}, 0
+    for i in range(len(data) - 7):
+        v = int.from_bytes(data[i:i + 8], "little") & ((1 << (8 * hash_len)) - 1)
+        h = ((v * 0x1E35A7BD1E35A7BD) & ((1 << 64) - 1)) >> (64 - table_bits)
+        w = data[i:i + hash_len]
+        n += h in seen and seen[h] != w
+        seen[h] = w
+    return n
+
+
+def test_hand_traced_queue_kats():
+    """known answers traced by hand through m4.go:187-259 (three
+    pending matches: cases 213 / 221 / default with clip, the re-search of a
+    trimmed match, the score gates, penalty 275 vs 0) -- see cases.hand_kats.
+    Both restatements and the host build of the product's parse header must
+    reproduce them; the traces assume no accidental bucket collision."""
+    for name, (kw, data, exp, reaches) in hand_kats().items():
+        assert _bucket_collisions(data) == 0, name
+        assert same(OracleM4(**kw).FindMatches(data), exp), (name, reaches)
+        assert same(M4Py(**kw).FindMatches([], data), exp), (name, reaches)
+        assert same(sim(data, **kw), exp), (name, reaches)
+        for sub in (16, 64):
+            assert same(sim_k3(data, sub, **kw)[0], exp), (name, sub)
 
 
 def test_golden_vectors():
@@ -78,6 +105,21 @@ def test_two_restatements_agree_streaming_with_slide():
         assert replay(a, blk, hist) == blk
         hist += blk
     assert same(o.FindMatches(b""), p.FindMatches([], b""))
+
+
+def test_streaming_slide_without_chain():
+    """history slide (m4.go:82-99) with ChainLength 0: only the table is rebased"""
+    kw = dict(MaxDistance=3000, DistanceBitCost=66)
+    data = synth.text(30000, 28)
+    o, p = OracleM4(**kw), M4Py(**kw)
+    hist = b""
+    for pos in range(0, len(data), 2048):
+        blk = data[pos:pos + 2048]
+        a = o.FindMatches(blk)
+        assert same(a, p.FindMatches([], blk)), pos
+        assert replay(a, blk, hist) == blk
+        hist += blk
+    assert o.history_len() < len(data)  # it did slide
 
 
 def test_seeded_repeat_distance():
@@ -245,3 +287,15 @@ def test_encoder_reset_determinism():
     enc.Reset()
     assert run() == a
     assert brotli_decompress(a, len(data)) == data
+
+
+@pytest.mark.skipif(bool(os.environ.get("M4G_ORACLE_SO")), reason="already inside the coverage run")
+def test_oracle_branch_coverage():
+    """tools/oracle_coverage.py: every reachable branch of the oracle's parse is
+    taken by this file's inputs (report: profiles/oracle_coverage.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oracle_coverage.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
