@@ -23,6 +23,14 @@ PARAMS_MISC = [
 ]
 
 
+def opticks() -> bytes:
+    """testdata/Isaac.Newton-Opticks.txt, the file every M4 test and benchmark of the
+    reference runs on (brotli_test.go:730-780); committed as a data fixture."""
+    import os
+    return open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "Isaac.Newton-Opticks.txt"), "rb").read()
+
+
 def edge_inputs():
     rng = np.random.default_rng(7)
     return {

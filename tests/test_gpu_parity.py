@@ -7,7 +7,7 @@ import pytest
 
 from brotli_amd import m4, synth
 from cases import (KATS, PARAMS_D, PARAMS_FAST_KAT, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs,
-                   fast_path_kat, hand_kats)
+                   fast_path_kat, hand_kats, opticks)
 from oracle_lib import OracleEncoder, OracleM4, brotli_decompress, histograms, replay
 
 pytestmark = pytest.mark.gpu
@@ -84,8 +84,8 @@ def test_streaming_blocks_p1(kw):
 
 def test_roundtrip_through_writer():
     """brotli_test.go:626-649 `test()`: Writer{M4, Encoder, 1<<16} -> decoder."""
-    data = synth.text(567198, 1)  # size of testdata/Isaac.Newton-Opticks.txt
-    for kw in PARAMS_REF_TESTS[:2]:
+    data = opticks()  # testdata/Isaac.Newton-Opticks.txt (BASELINE config 1)
+    for kw in PARAMS_REF_TESTS[:3] + [PARAMS_G]:
         buf = io.BytesIO()
         w = m4.Writer(buf, m4.M4(**kw), OracleEncoder(), 1 << 16)
         w.Write(data)

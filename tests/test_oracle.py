@@ -10,7 +10,7 @@ import pytest
 
 from brotli_amd import synth
 from cases import (KATS, PARAMS_D, PARAMS_FAST_KAT, PARAMS_G, PARAMS_MISC, PARAMS_REF_TESTS, edge_inputs,
-                   fast_path_kat, hand_kats)
+                   fast_path_kat, hand_kats, opticks)
 from m4_py import M4Py
 from oracle_lib import (OracleEncoder, OracleM4, brotli_decompress, histograms, lib as olib,
                         replay)
@@ -253,10 +253,8 @@ def test_histograms_totals():
 @pytest.mark.parametrize("kw", PARAMS_REF_TESTS, ids=ids)
 def test_roundtrip_reference_criterion(kw):
     """brotli_test.go:626-649 test(): Writer{M4, Encoder, 1<<16} -> decoder -> equal."""
-    data = synth.text(567198, 1)  # the size of testdata/Isaac.Newton-Opticks.txt
-    path = os.environ.get("M4G_OPTICKS")  # the reference's file, when a checkout is supplied
-    if path and os.path.exists(path):
-        data = open(path, "rb").read()
+    data = opticks()  # the reference's own test file (tests/golden/)
+    assert len(data) == 567198
     stream, _ = OracleM4(**kw).compress(data, 1 << 16)
     assert brotli_decompress(stream, len(data)) == data
 
