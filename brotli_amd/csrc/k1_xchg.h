@@ -63,9 +63,11 @@ static_assert(k1x_lds_bytes(15) <= 160 * 1024, "LDS of one CU");
 // the entry must end up with the value of the highest such lane.
 __global__ __launch_bounds__(256) void kx_order_selftest(uint32_t *__restrict__ mismatches) {
   __shared__ uint32_t tab[4][64];
+  __shared__ uint32_t tadd[4][64]; // the same check for add-with-return (k1_split.h, counting sort)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t *t = tab[wave];
+  uint32_t *t = tab[wave], *ta = tadd[wave];
   t[lane] = 0;
+  ta[lane] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   uint32_t bad = 0;
@@ -73,20 +75,21 @@ __global__ __launch_bounds__(256) void kx_order_selftest(uint32_t *__restrict__ 
     const uint32_t range = 1u + (it * 7u + wave * 3u) % 64u;       // 1 .. 64 distinct addresses
     const uint32_t idx = ((lane + it) * 2654435761u >> 7) % range; // many lanes per address
     const uint32_t val = (it << 8 | lane) + 1;
-    const uint32_t before = t[idx];
+    const uint32_t before = t[idx], before_a = ta[idx];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t got = __hip_atomic_exchange(&t[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t got_a = __hip_atomic_fetch_add(&ta[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t after = t[idx];
-    uint32_t expect = before, expect_after = val;
+    uint32_t expect = before, expect_after = val, below = 0;
     for (uint32_t l = 0; l < 64; l++) {
       const uint32_t li = __shfl(idx, l), lv = __shfl(val, l);
-      if (li == idx && l < lane) expect = lv;
+      if (li == idx && l < lane) expect = lv, below++;
       if (li == idx && l > lane) expect_after = lv;
     }
-    if (got != expect || after != expect_after) bad++;
+    if (got != expect || after != expect_after || got_a != before_a + below) bad++;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }

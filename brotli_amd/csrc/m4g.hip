@@ -103,13 +103,19 @@ int k1_prepare(uint32_t *d_word = nullptr) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1x_chain_build<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)k1x_lds_bytes(kMaxPartBits)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1c_consume),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)k1c_lds_bytes(kMaxPartBits)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1c_scatter),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)k1c_lds_bytes(kMaxPartBits)));
   return M4G_OK;
 }
 
 // K1 variant: the exchange kernel (k1_xchg.h), unless M4G_K1_SORT is set or the
 // device failed the ordering self-test (then the sorting kernel, kernels.h).
 std::atomic<int> g_xchg_order[64]; // per device: 0 = not tested, 1 = ordered, 2 = not ordered
-std::atomic<int> g_k1_force{-1};   // test hook (m4g_debug_set_k1_variant): -1 = automatic, 0 = sort, 1 = exchange
+std::atomic<int> g_k1_force{-1};   // test hook (m4g_debug_set_k1_variant): -1 = automatic, 0 = sort, 1 = exchange, 2 = split
 bool k1_use_sort() {
   const int f = g_k1_force.load();
   if (f >= 0) return f == 0;
@@ -208,6 +214,23 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
   return M4G_OK;
 }
 
+// Buffers of the split K1 (k1_split.h): the bin-sorted keys of every tile and the
+// per-tile bin headers.  keys == nullptr: the caller has none (streaming handle,
+// the entry point that allocates nothing) and K1 is the one-kernel form.
+struct K1Split {
+  uint32_t *keys = nullptr; // one word per chain entry (same indexing as the chain array)
+  uint32_t *hdr = nullptr;  // njobs x kt_max x KP_BINS words
+  uint32_t kt_max = 0;      // tiles reserved per job
+};
+// The split form handles fresh-state jobs (batch chunks) whose table splits into at
+// most 4 LDS partitions x 16 owner waves = KP_BINS bins.
+bool k1_split_usable(const Params &p) {
+  const int f = g_k1_force.load();
+  if (f >= 0 && f != 2) return false;
+  static const bool off = std::getenv("M4G_K1_NOSPLIT") != nullptr;
+  return !off && p.table_bits >= 4 && p.table_bits <= kMaxPartBits + 2;
+}
+
 // Launches K1 + K3 for `njobs` jobs whose descriptors are already in d_jobs.
 // On return (stream order) counts[job] holds the job's match count and the
 // records sit in w.rs / w.st as described by w.desc.
@@ -215,7 +238,7 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
 // of one stream (null otherwise).
 int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
               uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, hipStream_t st,
-              const StreamInfo *d_si, uint32_t *d_table_out = nullptr) {
+              const StreamInfo *d_si, uint32_t *d_table_out = nullptr, const K1Split *split = nullptr) {
   const int pb = part_bits_of(p);
   const int nparts = 1 << (p.table_bits - pb);
   const int groups = (njobs + 7) / 8;
@@ -228,6 +251,23 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
   while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
   const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
   if (cb < 1 && !k1_use_sort()) return fail(M4G_ERR_TOO_LARGE, "buffer positions need all 32 bits");
+  if (split && split->keys && !d_si && !d_table_io && cb >= 1 && k1_split_usable(p) &&
+      (g_k1_force.load() == 2 || !k1_use_sort()) && kp_tiles(max_len) <= split->kt_max) {
+    const uint32_t gpj = (split->kt_max + KP_TPW - 1) / KP_TPW;
+    const int bin_bits = (p.table_bits - pb) + 4;
+    hipLaunchKernelGGL(k1p_partition, dim3((unsigned)njobs * gpj), dim3(KP_THREADS), 0, st, d_src, src_total,
+                       split->keys, split->hdr, d_jobs, njobs, split->kt_max, gpj, p.hash_len, p.table_bits, bin_bits, cb);
+    HIP_TRY(hipGetLastError());
+    static const bool image = std::getenv("M4G_K1C_SCATTER") == nullptr;
+    if (image)
+      hipLaunchKernelGGL(k1c_consume, g1, dim3(KP_THREADS), k1c_lds_bytes(pb), st, split->keys, split->hdr, d_chain,
+                         d_jobs, njobs, split->kt_max, p.table_bits, pb, cb);
+    else
+      hipLaunchKernelGGL(k1c_scatter, g1, dim3(KP_THREADS), k1s_lds_bytes(pb), st, split->keys, split->hdr, d_chain,
+                         d_jobs, njobs, split->kt_max, p.table_bits, pb, cb);
+    HIP_TRY(hipGetLastError());
+    return M4G_OK;
+  }
   if (!k1_use_sort()) {
     if (d_si)
       hipLaunchKernelGGL(k1x_chain_build<true>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), st, d_src, src_total, d_chain,
@@ -271,8 +311,8 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
 // K1 + K3 for `njobs` jobs whose descriptors are already in d_jobs.
 int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
                 uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, const SpecWork &w, uint32_t *d_counts,
-                uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid) {
-  int rc = launch_k1(p, d_src, src_total, max_len, d_chain, d_jobs, d_table_io, njobs, st, nullptr);
+                uint32_t *d_errors, hipStream_t st, hipEvent_t ev_mid, const K1Split *split = nullptr) {
+  int rc = launch_k1(p, d_src, src_total, max_len, d_chain, d_jobs, d_table_io, njobs, st, nullptr, nullptr, split);
   if (rc) return rc;
   if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st));
   return launch_parse(p, d_src, src_total, d_chain, d_jobs, njobs, w, d_counts, d_errors, st);
@@ -362,6 +402,8 @@ struct BatchWork {
   Job *d_jobs = nullptr;
   LongRun *d_long_runs = nullptr; // literal runs >= K5_HUGE set aside by K4 for k5b_long_literals
   uint32_t long_cap = 0;
+  K1Split split;                  // keys alias w.rs when that is large enough (dead until K3), else keys_own
+  uint32_t *keys_own = nullptr;
 };
 
 struct m4g_batch {
@@ -387,6 +429,8 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->W.d_errors);
   (void)hipFree(b->W.d_jobs);
   (void)hipFree(b->W.d_long_runs);
+  (void)hipFree(b->W.split.hdr);
+  (void)hipFree(b->W.keys_own);
   if (b->h_jobs) (void)hipHostFree(b->h_jobs);
   if (b->ev_jobs) (void)hipEventDestroy(b->ev_jobs);
   for (auto &e : b->ev)
@@ -432,6 +476,25 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
     std::string msg = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
     m4g_batch_destroy(b);
     return fail(M4G_ERR_NO_MEMORY, msg);
+  }
+  { // buffers of the split K1 (the test hook may switch variants later)
+    const size_t chain_bytes = (nbytes + 16 * max_chunks) * 4;
+    b->W.split.kt_max = kp_tiles((uint32_t)max_chunk_bytes);
+    if (p.table_bits >= 4 && p.table_bits <= kMaxPartBits + 2 && b->W.split.kt_max > 0) {
+      const size_t rs_bytes = b->W.w.blocks * b->W.w.L.slot * sizeof(Rec);
+      if (rs_bytes >= chain_bytes) {
+        b->W.split.keys = reinterpret_cast<uint32_t *>(b->W.w.rs);
+      } else if ((e = hipMalloc(&b->W.keys_own, chain_bytes + 4096)) == hipSuccess) {
+        b->W.split.keys = b->W.keys_own;
+      }
+      if (e == hipSuccess)
+        e = hipMalloc(&b->W.split.hdr, max_chunks * (size_t)b->W.split.kt_max * KP_BINS * 4);
+      if (e != hipSuccess) {
+        std::string msg = std::string("hipMalloc K1 key workspace: ") + hipGetErrorString(e);
+        m4g_batch_destroy(b);
+        return fail(M4G_ERR_NO_MEMORY, msg);
+      }
+    }
   }
   for (auto &ev : b->ev) {
     if (hipEventCreate(&ev) != hipSuccess) {
@@ -483,7 +546,7 @@ int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, co
   HIP_TRY(hipMemsetAsync(W.d_errors, 0, 64, st));
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
   int rc = launch_find(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, W.w, W.d_counts,
-                       W.d_errors, st, ev ? ev[1] : nullptr);
+                       W.d_errors, st, ev ? ev[1] : nullptr, &W.split);
   if (rc) return rc;
   if (ev) HIP_TRY(hipEventRecord(ev[2], st));
   uint32_t *n_long = W.d_errors + 8; // zeroed with d_errors above
@@ -740,7 +803,11 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
   dim3 g1((unsigned)(((njobs + 7) / 8) * 8 * nparts));
   HIP_TRY(hipEventRecord(b->ev[0], nullptr));
   for (int r = 0; r < reps; r++)
-    if (k1_use_sort())
+    if (dbg < 0) { // the variant a plan run would use (split K1 when applicable)
+      if (int rc = launch_k1(b->p, d_src, src_total, (uint32_t)b->max_chunk_bytes, b->W.d_chain, b->W.d_jobs, nullptr,
+                             njobs, nullptr, nullptr, nullptr, &b->W.split))
+        return rc;
+    } else if (k1_use_sort())
       hipLaunchKernelGGL(k1_chain_build<false>, g1, dim3(K1_THREADS), k1_lds_bytes(pb), nullptr, d_src, src_total,
                          b->W.d_chain, b->W.d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
     else
@@ -759,7 +826,7 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
 // process.  m4g_debug_k1_run: K1 alone over the job list of the plan's last run,
 // chain entries written to the caller's buffer of m4g_debug_chain_words(b) words
 // (so a test can compare the two kernels' chain arrays on the device).
-extern "C" void m4g_debug_set_k1_variant(int v) { g_k1_force.store(v < 0 ? -1 : (v ? 1 : 0)); }
+extern "C" void m4g_debug_set_k1_variant(int v) { g_k1_force.store(v < 0 ? -1 : (v > 2 ? 1 : v)); }
 extern "C" uint64_t m4g_debug_chain_words(m4g_batch *b) {
   return b ? (uint64_t)(b->max_chunks * b->max_chunk_bytes + 16 * b->max_chunks) + 1024 : 0;
 }
@@ -769,7 +836,7 @@ extern "C" int m4g_debug_k1_run(m4g_batch *b, const uint8_t *d_src, uint64_t src
     return fail(M4G_ERR_BAD_PARAM, "bad argument (run the plan on these chunks first)");
   HIP_TRY(hipSetDevice(b->device));
   return launch_k1(b->p, d_src, src_total, (uint32_t)b->max_chunk_bytes, d_chain_out, b->W.d_jobs, nullptr, njobs,
-                   static_cast<hipStream_t>(hip_stream), nullptr);
+                   static_cast<hipStream_t>(hip_stream), nullptr, nullptr, &b->W.split);
 }
 
 // Diagnostic (not part of include/m4g.h): which K1 kernel the device gets --

@@ -123,7 +123,7 @@ def test_k1_variants_agree_on_1gib_of_mixed_input():
     words = int(L.m4g_debug_chain_words(plan._h))
     chains = []
     try:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):  # sorting kernel, exchange kernel, split K1 (k1_split.h)
             L.m4g_debug_set_k1_variant(variant)
             ch = torch.zeros(words, dtype=torch.int32, device=dev)
             rc = L.m4g_debug_k1_run(plan._h, d_src.data_ptr(), n * C, C, ch.data_ptr(), None)
@@ -134,6 +134,7 @@ def test_k1_variants_agree_on_1gib_of_mixed_input():
         L.m4g_debug_set_k1_variant(-1)
     assert int((chains[0] != 0).sum()) > n * C // 2  # the arrays hold real entries
     assert torch.equal(chains[0], chains[1])
+    assert torch.equal(chains[1], chains[2])
     # and they are the reference's chain (low 31 bits = delta), on a sample of chunks
     for c in (0, 700, 897, 898, 899):
         chunk = host[c * n:(c + 1) * n]
