@@ -42,7 +42,10 @@ constexpr int KP_WAVE_SPAN = 64 * KP_ROWS;          // consecutive positions of 
 constexpr int KP_TILE = KP_THREADS * KP_ROWS;       // 3072 positions: ~48 keys per bin on average
 constexpr int KP_BINS = 64;                         // <= 4 partitions x 16 owner waves
 constexpr int KP_CSTRIDE = KP_BINS + 1;             // odd stride: a wave's counters spread over the banks
-constexpr int KP_TPW = 4;                           // tiles per k1p workgroup (consecutive, one job)
+#ifndef M4G_KP_TPW
+#define M4G_KP_TPW 4
+#endif
+constexpr int KP_TPW = M4G_KP_TPW;                         // tiles per k1p workgroup (consecutive, one job)
 constexpr int KP_KEY_IDX_SHIFT = 17;                // key = index in the owner's slice << 17 | rel << cb | check bits
 constexpr uint32_t KP_EMPTY = 0xFFFFFFFFu;          // tile image word without a chain entry (no entry has this value)
 static_assert(KP_TILE <= 4096, "tile position must fit the key");
@@ -282,7 +285,10 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_scatter(
 // the headers of step s+2 are in flight.  Loads are issued back to back and
 // pinned with empty asm statements -- the compiler otherwise sinks each load into
 // the branch that uses it and waits for it there, one memory round trip per tile.
-constexpr uint32_t KC_G = 16;
+#ifndef M4G_KC_G
+#define M4G_KC_G 16
+#endif
+constexpr uint32_t KC_G = M4G_KC_G;
 __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
     const uint32_t *__restrict__ keys_base, const uint32_t *__restrict__ hdr_base,
     uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, int njobs, uint32_t kt_max,
@@ -348,6 +354,21 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
   load_keys(0, h0, k0);
   lds_barrier(); // table and images initialised
 
+  // The store phase of tile t-1 runs inside iteration t, around the exchanges of tile t: one barrier per
+  // tile, and the LDS round trips of the two halves overlap within a wave.
+  // Barrier at the top of iteration t: image (t-1) & 1 is complete (every wave has finished tile t-1), and
+  // image t & 1 has been emptied again (its words were stored and reset during iteration t-1).
+  auto store_tile = [&](const uint32_t *ent, uint32_t *img, uint32_t sb) {
+    // every wave stores 64 consecutive positions per instruction; only this partition's words are set
+#pragma unroll
+    for (int j = 0; j < KP_ROWS; j++) {
+      const uint32_t rel = j * KP_THREADS + tid;
+      if (ent[j] != KP_EMPTY) {
+        chain[sb + rel] = ent[j];
+        img[rel] = KP_EMPTY;
+      }
+    }
+  };
 #pragma unroll 1
   for (uint32_t tb = 0; tb < ntiles; tb += KC_G) {
     pin(k0); // requested one step ago
@@ -359,7 +380,11 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
       const uint32_t t = tb + u;
       if (t >= ntiles) break; // workgroup-uniform
       const uint32_t sb = t * KP_TILE;
-      uint32_t *img = res + (t & 1) * KP_TILE;
+      uint32_t *img = res + (t & 1) * KP_TILE, *imgp = res + ((t & 1) ^ 1) * KP_TILE;
+      uint32_t ent[KP_ROWS];
+      if (t > 0) lds_barrier();
+#pragma unroll
+      for (int j = 0; j < KP_ROWS; j++) ent[j] = t > 0 ? imgp[j * KP_THREADS + tid] : KP_EMPTY;
       const uint32_t n = h0[u] & 0xFFFFu;
       const uint32_t vbase = sb << cb; // table value = vbase + low key bits = position << cb | check bits
       {
@@ -390,19 +415,7 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
           }
         }
       }
-      lds_barrier(); // the image of tile t is complete
-      // every wave stores 64 consecutive positions per instruction; only this partition's words are set
-      uint32_t ent[KP_ROWS];
-#pragma unroll
-      for (int j = 0; j < KP_ROWS; j++) ent[j] = img[j * KP_THREADS + tid];
-#pragma unroll
-      for (int j = 0; j < KP_ROWS; j++) {
-        const uint32_t rel = j * KP_THREADS + tid;
-        if (ent[j] != KP_EMPTY) {
-          chain[sb + rel] = ent[j];
-          img[rel] = KP_EMPTY;
-        }
-      }
+      store_tile(ent, imgp, sb - KP_TILE); // (nothing in iteration 0: every word is KP_EMPTY)
     }
 #pragma unroll
     for (uint32_t u = 0; u < KC_G; u++) {
@@ -410,6 +423,14 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
       h1[u] = h2[u];
       k0[u] = k1[u];
     }
+  }
+  lds_barrier(); // the image of the last tile is complete
+  {
+    uint32_t *img = res + ((ntiles - 1) & 1) * KP_TILE;
+    uint32_t ent[KP_ROWS];
+#pragma unroll
+    for (int j = 0; j < KP_ROWS; j++) ent[j] = img[j * KP_THREADS + tid];
+    store_tile(ent, img, (ntiles - 1) * KP_TILE);
   }
 }
 
