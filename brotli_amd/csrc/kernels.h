@@ -1412,6 +1412,10 @@ __global__ __launch_bounds__(K5B_THREADS) void k5b_long_literals(
   }
 }
 
+} // namespace m4g
+#include "k6_encode.h"
+namespace m4g {
+
 // ---------------------------------------------------------------------------
 // KS: streaming helpers.
 // ---------------------------------------------------------------------------

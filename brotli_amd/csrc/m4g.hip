@@ -15,6 +15,9 @@
 #include <vector>
 
 #include "kernels.h"
+#include "enc_host.h"
+
+#include <thread>
 
 using namespace m4g;
 
@@ -417,6 +420,11 @@ struct m4g_batch {
   bool timing = false, ran = false;
   hipEvent_t ev[5] = {};
   hipStream_t last_stream = nullptr;
+  // m4g_batch_encode: device buffers, grown on demand
+  uint32_t *enc_tables = nullptr;  // K6_TAB words per chunk
+  uint64_t *enc_pos = nullptr, *enc_bits = nullptr; // per chunk: body bit position / bits written
+  uint32_t *enc_words = nullptr;   // the stream
+  size_t enc_words_cap = 0;
 };
 
 extern "C" void m4g_batch_destroy(m4g_batch *b) {
@@ -431,6 +439,10 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->W.d_long_runs);
   (void)hipFree(b->W.split.hdr);
   (void)hipFree(b->W.keys_own);
+  (void)hipFree(b->enc_tables);
+  (void)hipFree(b->enc_pos);
+  (void)hipFree(b->enc_bits);
+  (void)hipFree(b->enc_words);
   if (b->h_jobs) (void)hipHostFree(b->h_jobs);
   if (b->ev_jobs) (void)hipEventDestroy(b->ev_jobs);
   for (auto &e : b->ev)
@@ -646,6 +658,114 @@ extern "C" int m4g_batch_status(m4g_batch *b) {
   uint32_t err = 0;
   HIP_TRY(hipMemcpy(&err, b->W.d_errors, 4, hipMemcpyDeviceToHost));
   return status_from_error_word(err);
+}
+
+// ===========================================================================
+// GPU encoder: brotli.Encoder.Encode for every chunk of a batch (include/m4g.h,
+// m4g_batch_encode).  Pass 1 ran on the GPU already (K5: histograms + codes);
+// the prefix codes are built here on host threads (enc_host.h), pass 2 is K6.
+// ===========================================================================
+extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks, const m4g_match *d_out,
+                                    const uint64_t *d_out_off, const m4g_histo *d_histos, const m4g_code *d_codes,
+                                    int flags, uint8_t *stream_out, size_t stream_cap, void *hip_stream, float *ms_out) {
+  using namespace m4g_enc;
+  if (!b || !d_out_off || !d_histos || !d_codes || (nchunks && (!d_src || !d_out)))
+    return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (b->last_off.size() != nchunks + 1)
+    return fail(M4G_ERR_BAD_PARAM, "m4g_batch_encode: run the plan on these chunks first (m4g_batch_run_device_codes)");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const auto t_begin = std::chrono::steady_clock::now();
+  // the histograms of the run (its kernels must have finished)
+  std::vector<uint32_t> histos(nchunks * 1024);
+  HIP_TRY(hipStreamSynchronize(st));
+  if (nchunks) HIP_TRY(hipMemcpy(histos.data(), d_histos, nchunks * sizeof(m4g_histo), hipMemcpyDeviceToHost));
+  // per chunk: meta-block header + prefix codes, code tables, body length -- on host threads
+  static const CodeLengthCode cl;
+  static const CmdExtra cx;
+  std::vector<ChunkPlan> plans(nchunks);
+  std::vector<uint32_t> tables(nchunks * (size_t)K6_TAB);
+  {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nt = (unsigned)std::min<size_t>(hw, (nchunks + 31) / 32 + 1);
+    auto work = [&](unsigned t) {
+      for (size_t c = t; c < nchunks; c += nt) {
+        const uint64_t len = b->last_off[c + 1] - b->last_off[c];
+        if (len == 0) continue; // Encode writes nothing for an empty block (encoder.go:24-31)
+        plan_chunk(histos.data() + c * 1024, (size_t)len, tables.data() + c * K6_TAB, plans[c], cl, cx);
+        plans[c].prologue.flush();
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  const auto t_planned = std::chrono::steady_clock::now();
+  // bit positions (one bit writer for the whole stream: bitwriter.go state carries over between blocks)
+  std::vector<uint64_t> body_pos(nchunks + 1), pro_pos(nchunks);
+  uint64_t pos = (flags & 1) ? 4 : 0; // stream header: WBITS = 24 (encoder.go:19-22)
+  for (size_t c = 0; c < nchunks; c++) {
+    pro_pos[c] = pos;
+    body_pos[c] = pos + plans[c].prologue.total;
+    pos = body_pos[c] + plans[c].body_bits;
+  }
+  const uint64_t end_pos = pos;
+  if (flags & 2) pos += 2; // ISLAST + ISEMPTY (encoder.go:156-159)
+  const uint64_t nbytes = (pos + 7) / 8;
+  if (nbytes > stream_cap) return -(int64_t)nbytes;
+  if (!stream_out && nbytes) return fail(M4G_ERR_BAD_PARAM, "stream_out is NULL");
+  const size_t nwords = (size_t)(nbytes / 4 + 2);
+  if (nchunks > 0) {
+    if (!b->enc_tables) {
+      if (hipMalloc(&b->enc_tables, b->max_chunks * (size_t)K6_TAB * 4) != hipSuccess ||
+          hipMalloc(&b->enc_pos, b->max_chunks * 8) != hipSuccess || hipMalloc(&b->enc_bits, b->max_chunks * 8) != hipSuccess)
+        return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the encoder tables failed");
+    }
+    if (nwords > b->enc_words_cap) {
+      (void)hipFree(b->enc_words);
+      b->enc_words = nullptr;
+      b->enc_words_cap = 0;
+      if (hipMalloc(&b->enc_words, nwords * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the stream failed");
+      b->enc_words_cap = nwords;
+    }
+    HIP_TRY(hipMemsetAsync(b->enc_words, 0, nwords * 4, st));
+    HIP_TRY(hipMemcpyAsync(b->enc_tables, tables.data(), nchunks * (size_t)K6_TAB * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->enc_pos, body_pos.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    hipLaunchKernelGGL(k6_emit_bodies, dim3((unsigned)nchunks), dim3(K6_THREADS), 0, st, d_src,
+                       reinterpret_cast<const uint32_t *>(d_out), reinterpret_cast<const CodeRec *>(d_codes), b->W.d_jobs,
+                       d_out_off, b->enc_tables, b->enc_pos, b->enc_words, b->enc_bits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    std::vector<uint64_t> written(nchunks);
+    HIP_TRY(hipMemcpyAsync(written.data(), b->enc_bits, nchunks * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(stream_out, b->enc_words, nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t c = 0; c < nchunks; c++)
+      if (written[c] != plans[c].body_bits)
+        return fail(M4G_ERR_INTERNAL, "m4g_batch_encode: a chunk's body length differs from the histogram prediction "
+                                      "(d_out / d_histos / d_codes are not from the same run?)");
+    if (ms_out) HIP_TRY(hipEventElapsedTime(&ms_out[1], b->ev[0], b->ev[1]));
+  } else if (nbytes) {
+    std::memset(stream_out, 0, nbytes);
+  }
+  // the host-written fields share bytes with the bodies: OR them in
+  if (flags & 1) {
+    const uint8_t hdr = 15;
+    or_bits(stream_out, 0, &hdr, 4);
+  }
+  for (size_t c = 0; c < nchunks; c++)
+    if (plans[c].prologue.total) or_bits(stream_out, pro_pos[c], plans[c].prologue.dst.data(), plans[c].prologue.total);
+  if (flags & 2) {
+    const uint8_t fin = 3;
+    or_bits(stream_out, end_pos, &fin, 2);
+  }
+  if (ms_out) {
+    ms_out[0] = std::chrono::duration<float, std::milli>(t_planned - t_begin).count();
+    ms_out[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return (int64_t)nbytes;
 }
 
 // ===========================================================================

@@ -97,6 +97,9 @@ def lib():
         L.m4g_batch_set_timing.argtypes = [vp, ctypes.c_int]
         L.m4g_batch_set_timing.restype = None
         L.m4g_batch_status.argtypes = [vp]
+        L.m4g_batch_encode.argtypes = [vp, vp, sz, vp, vp, vp, vp, ctypes.c_int, vp, sz, vp,
+                                       ctypes.POINTER(ctypes.c_float)]
+        L.m4g_batch_encode.restype = ctypes.c_int64
         L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
@@ -364,6 +367,24 @@ class BatchPlan:
                                         d_histos.data_ptr() if d_histos is not None else None,
                                         stream if stream else None)
         _check(rc, "m4g_batch_run_device")
+
+
+    def encode(self, d_src, nchunks: int, d_out, d_out_off, d_histos, d_codes, first: bool = True,
+               last: bool = True, stream: int = 0, cap: "int | None" = None):
+        """m4g_batch_encode: brotli.Encoder.Encode for every chunk of the plan's last
+        run (which must have produced d_histos and d_codes), pass 2 on the GPU.
+        Returns (stream bytes, [host ms, kernel ms, total ms])."""
+        if cap is None:
+            cap = int(d_src.numel()) + (nchunks + 1) * 1024 + 64
+        buf = np.zeros(cap, dtype=np.uint8)
+        ms = (ctypes.c_float * 3)()
+        r = lib().m4g_batch_encode(self._h, d_src.data_ptr(), nchunks, d_out.data_ptr(), d_out_off.data_ptr(),
+                                   d_histos.data_ptr(), d_codes.data_ptr(), (1 if first else 0) | (2 if last else 0),
+                                   buf.ctypes.data, cap, stream if stream else None, ms)
+        _check(r, "m4g_batch_encode")
+        if r < 0:
+            raise M4GError(f"m4g_batch_encode: stream_cap too small, need {-r}")
+        return buf[:r].tobytes(), [float(ms[k]) for k in range(3)]
 
 
 def run_device_noalloc(d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0,

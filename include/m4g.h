@@ -209,6 +209,36 @@ int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
                                uint64_t *out_off, size_t out_cap,
                                m4g_histo *histos);
 
+/* Replaces: brotli.Encoder.Encode(dst, chunk, matches, false) called for every
+ * chunk of the batch in chunk order on ONE Encoder (encoder.go:17-161), i.e.
+ * what matchfinder.Writer does after FindMatches (matchfinder.go:84) -- the
+ * serial stage that bounds a V2 pipeline.  Input: the device-resident results
+ * of the plan's last m4g_batch_run_device_codes call on these chunks (d_out,
+ * d_out_off, d_histos, d_codes; d_src as in that call).  Pass 1 (encoder.go:
+ * 44-105) was done by that call; here the host builds the three prefix codes
+ * of every chunk from its histograms (encoder.go:107-120, on host threads) and
+ * the GPU writes every chunk's commands, literals and distances (encoder.go:
+ * 122-154) at their final bit positions of one stream (bitwriter.go:19-33:
+ * meta-blocks are not byte aligned).
+ *   flags bit 0: this call starts a stream: write the stream header
+ *                (encoder.go:19-22); bit 1: it also ends it: ISLAST + ISEMPTY
+ *                and padding to a byte (encoder.go:156-159).  Both set = one
+ *                complete brotli stream holding the chunks as consecutive
+ *                meta-blocks (Writer.Write(all chunks); Writer.Close()).
+ *                Without bit 1 the last byte may be partial (zero padded): a
+ *                caller that continues the stream must carry those bits over.
+ *   stream_out : host memory, stream_cap bytes.  Returns the stream length in
+ *                bytes, -(needed) when stream_cap is too small, or an M4G_ERR_*.
+ *   ms_out     : nullable, 3 floats: host code building, K6 kernel, whole call (ms).
+ * Synchronises hip_stream.  The bytes equal Encoder.Encode's up to the order in
+ * which chooseBitDepths (brotli_bit_stream.go:571) sorts symbols of equal count
+ * (Go's unstable sort; ascending symbol here): always a valid stream. */
+int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks,
+                         const m4g_match *d_out, const uint64_t *d_out_off,
+                         const m4g_histo *d_histos, const m4g_code *d_codes,
+                         int flags, uint8_t *stream_out, size_t stream_cap,
+                         void *hip_stream, float *ms_out);
+
 /* Kernel-side outcome of the plan's most recent m4g_batch_run_device[_codes]
  * call.  Those calls only enqueue work and return before it runs, so conditions
  * the kernels detect cannot come back through their return value: this call
