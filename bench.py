@@ -148,6 +148,8 @@ def parse_args():
     ap.add_argument("--cpu-1thread-chunks", type=int, default=384)
     ap.add_argument("--encode-sample-chunks", type=int, default=48)
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-gpu-encode", action="store_true",
+                    help="skip the m4g_batch_encode leg (Encoder pass 2 on the GPU, SURVEY 8f.2)")
     ap.add_argument("--e2e-sample-chunks", type=int, default=512)
     return ap.parse_args()
 
@@ -248,6 +250,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- Encoder pass 2 on the GPU (untimed for `value`; reported beside the CPU Encode time) ----
+    gpu_encode = None
+    if rank == 0 and d_h is not None and not args.no_gpu_encode:
+        dc = d_codes if d_codes is not None else torch.empty(2 * out_cap, dtype=torch.int32, device=dev)
+        plan.run(d_src, off, d_out, d_off, d_h, stream, d_codes=dc)
+        plan.status()
+        pin = m4.PinnedBuffer(n * C // 2 + (C + 1) * 1024 + 64)
+        try:
+            plan.encode(d_src, C, d_out, d_off, d_h, dc, out=pin.array)  # warm: allocates the stream buffer
+            nbytes, ems = plan.encode(d_src, C, d_out, d_off, d_h, dc, out=pin.array)
+            gpu_encode = {"stream_bytes": nbytes, "ms": ems, "first": bytes(pin.array[:1 << 20])}
+        except m4.M4GError as e:  # (incompressible input does not fit the half-size buffer)
+            gpu_encode = {"error": str(e)}
+        pin.close()
+        if d_codes is None:
+            del dc
 
     total_matches = int(d_off[C].item())
     if total_matches > out_cap:
@@ -402,6 +421,23 @@ def main():
                 "sample": f"restated brotli.Encoder.Encode (oracle/encoder_ref.c) on {len(enc_chunks)} chunks, one "
                           f"thread: the serial stage a V2 pipeline runs after match finding (SURVEY section 7)",
             }
+    if gpu_encode and "ms" in gpu_encode:
+        # byte identity of the stream's first meta-block with the restated Encoder (the tests check whole streams)
+        enc0 = OracleEncoder()
+        ref0 = enc0.Encode(host[:n], ref_lists[0] if 0 in ref_lists else got_all[int(o[0]):int(o[1])], False)
+        k = max(0, len(ref0) - 8)
+        host_ms, k6_ms, all_ms = gpu_encode["ms"]
+        out["gpu_encode"] = {
+            "value": round(C * n / (all_ms * 1e-3) / 1e9, 3), "unit": "GB/s", "ms_total": round(all_ms, 2),
+            "ms_host_prefix_codes": round(host_ms, 2), "ms_k6_emit_bits": round(k6_ms, 2),
+            "stream_bytes": gpu_encode["stream_bytes"], "compression_ratio": round(C * n / gpu_encode["stream_bytes"], 4),
+            "first_metablock_equals_restated_encoder": gpu_encode["first"][:k] == ref0[:k],
+            "sample": f"m4g_batch_encode over all {C} chunks of rank 0 (one brotli stream, one meta-block per chunk): "
+                      f"D2H of the histograms, prefix codes on host threads, K6 on the GPU, D2H of the stream into "
+                      f"page-locked memory; ms_total is the whole call",
+        }
+    elif gpu_encode:
+        out["gpu_encode"] = gpu_encode
     if not args.no_end_to_end and world == 1:
         # PCIe-inclusive rate of the host-memory API on a bounded sample: wall
         # clock from the first H2D enqueue to the last D2H completion (SURVEY

@@ -370,13 +370,18 @@ class BatchPlan:
 
 
     def encode(self, d_src, nchunks: int, d_out, d_out_off, d_histos, d_codes, first: bool = True,
-               last: bool = True, stream: int = 0, cap: "int | None" = None):
+               last: bool = True, stream: int = 0, cap: "int | None" = None, out: "np.ndarray | None" = None):
         """m4g_batch_encode: brotli.Encoder.Encode for every chunk of the plan's last
         run (which must have produced d_histos and d_codes), pass 2 on the GPU.
-        Returns (stream bytes, [host ms, kernel ms, total ms])."""
-        if cap is None:
-            cap = int(d_src.numel()) + (nchunks + 1) * 1024 + 64
-        buf = np.zeros(cap, dtype=np.uint8)
+        Returns (stream bytes, [host ms, kernel ms, total ms]); with `out` (a uint8
+        array, e.g. PinnedBuffer.array) the stream is left there and its length is
+        returned in place of the bytes."""
+        if out is not None:
+            buf, cap = out, out.size
+        else:
+            if cap is None:
+                cap = int(d_src.numel()) + (nchunks + 1) * 1024 + 64
+            buf = np.zeros(cap, dtype=np.uint8)
         ms = (ctypes.c_float * 3)()
         r = lib().m4g_batch_encode(self._h, d_src.data_ptr(), nchunks, d_out.data_ptr(), d_out_off.data_ptr(),
                                    d_histos.data_ptr(), d_codes.data_ptr(), (1 if first else 0) | (2 if last else 0),
@@ -384,7 +389,7 @@ class BatchPlan:
         _check(r, "m4g_batch_encode")
         if r < 0:
             raise M4GError(f"m4g_batch_encode: stream_cap too small, need {-r}")
-        return buf[:r].tobytes(), [float(ms[k]) for k in range(3)]
+        return (int(r) if out is not None else buf[:r].tobytes()), [float(ms[k]) for k in range(3)]
 
 
 def run_device_noalloc(d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0,
