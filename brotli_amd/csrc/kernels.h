@@ -795,9 +795,51 @@ __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
 }
 
 // Memory accessor for code that every lane of a wave runs in lockstep with
-// identical arguments (k3c): a long forward extension compares 64 x 8 bytes per
-// step instead of 8.
-struct WaveMem : GlobalMem {};
+// identical arguments (k3c's serial re-stitch of one sub-block).  Read straight
+// from global memory, every position the parse visits costs several DEPENDENT
+// round trips (chain entry, near bytes, far bytes) with nothing to hide them
+// behind -- one wave per chunk -- which made inputs built from long repeats
+// crawl (profiles/r01_kind_probe.log: 6-13 GB/s).  So the wave first copies the
+// sub-block's bytes [w0 - K3C_BACK, w0 + wn + K3C_FWD) and chain entries
+// [w0, w0 + wn) into LDS with full-width loads; reads inside the window are LDS
+// broadcasts, only match sources and overlong extensions go to memory.  A long
+// forward extension compares 64 x 8 bytes per step instead of 8.
+constexpr int K3C_WIN = 1024;  // positions staged (larger sub-blocks: the rest is read from memory)
+constexpr int K3C_BACK = 16, K3C_FWD = 48;
+constexpr int K3C_SRC_DW = (K3C_BACK + K3C_WIN + K3C_FWD) / 4 + 1;
+constexpr int K3C_RECS = 288;  // speculative records of the block staged alongside (more: read from memory)
+struct WaveMem : GlobalMem {
+  const uint32_t *lsrc; // LDS image of bytes [w0 - K3C_BACK, w0 - K3C_BACK + nbytes)
+  const uint32_t *lch;  // LDS image of chain[w0 .. w0 + wn)
+  int32_t w0, wn, nbytes;
+  __device__ __forceinline__ uint8_t ld8(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + K3C_BACK);
+    if (o < (uint32_t)nbytes) return (uint8_t)(lsrc[o >> 2] >> (8 * (o & 3)));
+    return src[p];
+  }
+  __device__ __forceinline__ uint32_t ld32(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + K3C_BACK);
+    if (o <= (uint32_t)nbytes - 4) { // (nbytes >= 64; `o + 4 <= nbytes` would wrap for positions just below the window)
+      const uint32_t w = o >> 2;
+      return __builtin_amdgcn_alignbyte(lsrc[w + 1], lsrc[w], o & 3);
+    }
+    return m4g::ld32(src + p);
+  }
+  __device__ __forceinline__ uint64_t ld64(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + K3C_BACK);
+    if (o <= (uint32_t)nbytes - 8) {
+      const uint32_t w = o >> 2, sh = o & 3;
+      const uint32_t d0 = lsrc[w], d1 = lsrc[w + 1], d2 = lsrc[w + 2];
+      return ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sh);
+    }
+    return m4g::ld64(src + p);
+  }
+  __device__ __forceinline__ uint32_t chain_at(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0);
+    if (o < (uint32_t)wn) return lch[o];
+    return chain[p];
+  }
+};
 __device__ __forceinline__ int32_t extend_fwd(const WaveMem &M, int32_t len, int32_t i, int32_t j) {
   const int32_t lane = (int32_t)(threadIdx.x & 63);
   while ((int64_t)j + 64 * 8 + 8 < (int64_t)len) {
@@ -811,7 +853,55 @@ __device__ __forceinline__ int32_t extend_fwd(const WaveMem &M, int32_t len, int
     i += 64 * 8;
     j += 64 * 8;
   }
-  return extend_fwd(static_cast<const GlobalMem &>(M), len, i, j);
+  while (j + 8 < len) { // (the generic loop, spelled out: the overload set would pick this function again)
+    const uint64_t a = M.ld64(i), b = M.ld64(j);
+    if (a != b) return j + (int32_t)(__builtin_ctzll(a ^ b) >> 3);
+    i += 8;
+    j += 8;
+  }
+  while (j < len && M.ld8(i) == M.ld8(j)) {
+    i++;
+    j++;
+  }
+  return j;
+}
+// The same for the backward extension: 64 bytes per step (lane l compares the bytes l + 1 below).
+__device__ __forceinline__ int32_t extend_bwd(const WaveMem &M, int32_t pos, int32_t cand, int32_t nb, int32_t maxb) {
+  const int32_t lane = (int32_t)(threadIdx.x & 63);
+  while (nb < maxb) {
+    const int32_t k = nb + lane; // this lane's byte: k + 1 below pos / cand
+    const bool ne = k < maxb && M.ld8(pos - k - 1) != M.ld8(cand - k - 1);
+    const unsigned long long m = __ballot(ne);
+    if (m) return nb + (int32_t)__builtin_ctzll(m);
+    nb = min(nb + 64, maxb);
+  }
+  return nb;
+}
+// Wave-cooperative fill of the window of sub-block [bb, be) of a job whose buffer is src[0, len).
+// lsrc has K3C_SRC_DW words (the last one is the funnel shift's read-ahead), lch has K3C_WIN.
+__device__ __forceinline__ void k3c_stage(WaveMem &M, uint32_t *lsrc, uint32_t *lch, int32_t len, int32_t bb,
+                                          int32_t be, int lane) {
+  M.w0 = bb;
+  M.wn = min(be - bb, K3C_WIN);
+  M.nbytes = K3C_BACK + M.wn + K3C_FWD;
+  M.lsrc = lsrc;
+  M.lch = lch;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // earlier reads of the previous window are done
+  __builtin_amdgcn_wave_barrier();
+  for (int g = lane; g * 16 < M.nbytes; g += 64) {
+    const uint4 v = load_group(M.src, (int64_t)bb - K3C_BACK + 16 * g, (int64_t)len);
+    uint32_t *d = lsrc + 4 * g;
+    d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+  }
+  if (lane == 0) lsrc[(M.nbytes + 3) / 4] = 0;
+  for (int g = lane; g * 4 < M.wn; g += 64) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (4 * g + k < M.wn) lch[4 * g + k] = M.chain[bb + 4 * g + k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __global__ __launch_bounds__(64) void k3c_validate(
@@ -820,6 +910,9 @@ __global__ __launch_bounds__(64) void k3c_validate(
     const ParseState *__restrict__ E, const ParseState *__restrict__ Tout,
     BlockDesc *__restrict__ desc, uint32_t *__restrict__ counts, uint32_t *__restrict__ errors,
     int njobs, SpecLayout L, ParseParams P) {
+  __shared__ uint32_t c_src[K3C_SRC_DW + 1];
+  __shared__ uint32_t c_ch[K3C_WIN];
+  __shared__ Rec c_rec[K3C_RECS];
   const uint32_t job = blockIdx.x;
   if (job >= (uint32_t)njobs) return;
   const int lane = threadIdx.x;
@@ -837,6 +930,12 @@ __global__ __launch_bounds__(64) void k3c_validate(
   state_init(T, g.start, J.seed_prev);
   uint32_t err = 0;
   uint32_t c_valid = 0, c_fast = 0, c_slow = 0, c_skip = 0; // diagnostics (M4G_TRACE)
+#ifdef M4G_K3C_TIMING
+  uint64_t tk[4] = {0, 0, 0, 0}, tk0 = wall_clock64();
+#define K3C_TICK(b) do { const uint64_t n_ = wall_clock64(); tk[b] += n_ - tk0; tk0 = n_; } while (0)
+#else
+#define K3C_TICK(b) do {} while (0)
+#endif
   if (E[b0].error & kStateAborted) { // even block 0 was given up: parse from the initial state
     valid = false;
     k = 0;
@@ -896,6 +995,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
           k += extra + 1;
         }
       }
+      K3C_TICK(0);
     } else {
       // block k from the true state T (every lane runs the same code)
       const uint64_t t = b0 + k;
@@ -920,6 +1020,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
         }
         c_skip += covered_end - k;
         k = covered_end;
+        K3C_TICK(1);
         continue;
       }
       // Fast path.  T has nothing pending and stands at the block start, so it
@@ -966,6 +1067,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
           valid = true; // E[k] is the true end state, so block k+1's stitch stands
         }
         k++;
+        K3C_TICK(2);
         continue;
       }
       if (T.i >= be) c_skip++; else c_slow++;
@@ -974,7 +1076,17 @@ __global__ __launch_bounds__(64) void k3c_validate(
       WaveMem M;
       M.src = src;
       M.chain = chain;
-      const bool ok = stitch_block(M, len, P, g, (int32_t)k, rs + t * L.slot, n_spec, Ek, T, sink, keep);
+      k3c_stage(M, c_src, c_ch, len, bb, be, lane);
+      // the block's speculative records, which the stitch scans for a common flush, staged the same way
+      const Rec *spec = rs + t * L.slot;
+      if (n_spec <= (uint32_t)K3C_RECS) {
+        for (uint32_t r = lane; r < n_spec; r += 64) c_rec[r] = spec[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        spec = c_rec;
+      }
+      const bool ok = stitch_block(M, len, P, g, (int32_t)k, spec, n_spec, Ek, T, sink, keep);
       if (sink.n > L.slot) err |= 2u;
       if (lane == 0) {
         BlockDesc nd = d;
@@ -986,6 +1098,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
       off += sink.n + (n_spec - keep);
       if (ok) valid = true;
       k++;
+      K3C_TICK(3);
     }
   }
   if (T.error & kStateErrRange) err |= 1u;
@@ -996,6 +1109,9 @@ __global__ __launch_bounds__(64) void k3c_validate(
     atomicAdd(errors + 5, c_fast);
     atomicAdd(errors + 6, c_slow);
     atomicAdd(errors + 7, c_skip);
+#ifdef M4G_K3C_TIMING
+    for (int q = 0; q < 4; q++) atomicAdd(errors + 9 + q, (uint32_t)(tk[q] >> 4)); // 100 MHz ticks / 16
+#endif
   }
 }
 

@@ -118,6 +118,22 @@ M4G_HD int32_t extend_fwd(const Mem &M, int32_t len, int32_t i, int32_t j) {
   return j;
 }
 
+// Backward half of m4.go:330-333 beyond the first bytes: the largest n in [nb, maxb] such that the n
+// bytes before pos equal the n bytes before cand (nb of them are known to).
+template <class Mem>
+M4G_HD int32_t extend_bwd(const Mem &M, int32_t pos, int32_t cand, int32_t nb, int32_t maxb) {
+  // 8 bytes per step while 8 more fit (maxb <= cand and maxb <= pos: the reads stay inside the buffer);
+  // a match source is far memory, so every step is a round trip -- bytewise this loop was what made
+  // long back-extensions (repeated paragraphs) crawl
+  while (nb + 8 <= maxb) {
+    const uint64_t x = M.ld64(pos - nb - 8) ^ M.ld64(cand - nb - 8);
+    if (x != 0) return nb + (int32_t)(__builtin_clzll(x) >> 3);
+    nb += 8;
+  }
+  while (nb < maxb && M.ld8(pos - nb - 1) == M.ld8(cand - nb - 1)) nb++;
+  return nb;
+}
+
 // m4.go:328-339
 template <class Mem>
 M4G_HD AbsMatch extend2(const Mem &M, int32_t len, int32_t start, int32_t cand, int32_t lo) {
@@ -156,8 +172,7 @@ M4G_HD bool match_at(const Mem &M, int32_t len, int32_t pos, int32_t cand, int32
       const uint64_t y = cb ^ M.ld64(pos - 8);
       nb = y != 0 ? (int32_t)(__builtin_clzll(y) >> 3) : 8;
       if (nb > maxb) nb = maxb;
-      if (nb == 8)
-        while (nb < maxb && M.ld8(pos - nb - 1) == M.ld8(cand - nb - 1)) nb++;
+      if (nb == 8) nb = extend_bwd(M, pos, cand, nb, maxb);
     }
     m.start = pos - nb;
     m.match = cand - nb;
@@ -243,8 +258,7 @@ M4G_HD bool match_regs(const Mem &M, int32_t len, int32_t pos, int32_t cand, int
     const uint64_t y = cb ^ M.ld64(pos - 8);
     nb = y != 0 ? (int32_t)(__builtin_clzll(y) >> 3) : 8;
     if (nb > maxb) nb = maxb;
-    if (nb == 8)
-      while (nb < maxb && M.ld8(pos - nb - 1) == M.ld8(cand - nb - 1)) nb++;
+    if (nb == 8) nb = extend_bwd(M, pos, cand, nb, maxb);
   }
   m.start = pos - nb;
   m.match = cand - nb;

@@ -631,11 +631,14 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
                               d_out_off, out_cap, d_histos, d_codes, st, b->timing ? b->ev : nullptr);
   if (rc) return rc;
   if (std::getenv("M4G_TRACE_K3C")) { // diagnostics of the validation pass (forces a sync)
-    uint32_t w[8] = {};
+    uint32_t w[16] = {};
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(w, b->W.d_errors, sizeof(w), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "[m4g] k3c: %u scan steps, %u blocks accepted by the probe check, %u parsed serially, %u skipped (covered)\n",
                  w[4], w[5], w[6], w[7]);
+    if (w[9] | w[10] | w[11] | w[12]) // builds with M4G_K3C_TIMING: wave time per path, summed over the chunks
+      std::fprintf(stderr, "[m4g] k3c wave-ms: scan %.2f, covered skip %.2f, probe check %.2f, serial %.2f\n",
+                   w[9] * 16 / 1e5, w[10] * 16 / 1e5, w[11] * 16 / 1e5, w[12] * 16 / 1e5);
   }
   b->ran = true;
   b->last_stream = st;
