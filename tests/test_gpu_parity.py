@@ -243,6 +243,11 @@ def test_batch_inputs_that_defeat_the_speculation():
         np.concatenate([rnd[:70000], rnd[:70000], rnd[1000:n - 139000]]),  # far repeats inside noise
         np.concatenate([np.resize(np.frombuffer(b"xy", dtype=np.uint8), 50001), rnd[:n - 50001]]),
     ]
+    # the three "paragraphs repeated" rows of tools/kind_probe.py: long matches everywhere, long back-extensions
+    big = np.frombuffer(synth.text(1 << 20, 10), dtype=np.uint8)
+    for plen in (2000, 8192, 40000):
+        pool = [big[i * plen:(i + 1) * plen] for i in range(16)]
+        chunks.append(np.concatenate([pool[int(j)] for j in rng.integers(0, 16, n // plen + 1)])[:n])
     host = np.concatenate(chunks)
     for kw in (PARAMS_G, dict(MaxDistance=1 << 16, ChainLength=4, HashLen=5, DistanceBitCost=66)):
         out, o, h = _run_batch(host, n, len(chunks), kw)
