@@ -151,6 +151,7 @@ def parse_args():
     ap.add_argument("--no-gpu-encode", action="store_true",
                     help="skip the m4g_batch_encode leg (Encoder pass 2 on the GPU, SURVEY 8f.2)")
     ap.add_argument("--e2e-sample-chunks", type=int, default=512)
+    ap.add_argument("--e2e-persistent-chunks", type=int, default=2048)
     return ap.parse_args()
 
 
@@ -458,12 +459,34 @@ def main():
         t0 = time.perf_counter()
         m4.find_matches_batch(pin_in.array, sub_off, (local_rank,), True, out=pin_out.array.view(np.uint32), **kw)
         dt_pin = time.perf_counter() - t0
+        pin_in.close()
+        pin_out.close()
+        # the persistent handle (m4g_hostbatch_*): nothing allocated per run; a larger sample, as a serving
+        # loop would see it
+        ps = min(C, args.e2e_persistent_chunks)
+        hb = m4.HostBatch(ps, n, (local_rank,), **kw)
+        pin_in = m4.PinnedBuffer(n * ps)
+        pin_in.array[:] = host[:n * ps]
+        pin_out = m4.PinnedBuffer(12 * (total_matches * ps // C + (1 << 20)))
+        pin_out.array[:] = 0
+        hb.run(pin_in.array, off[:ps + 1], True, out=pin_out.array.view(np.uint32))  # warm
+        t0 = time.perf_counter()
+        pm, poff, ph = hb.run(pin_in.array, off[:ps + 1], True, out=pin_out.array.view(np.uint32))
+        dt_hb = time.perf_counter() - t0
+        same_as_device = bool((poff.astype(np.int64) == o[:ps + 1]).all()) and \
+            bool((pm == got_all[:int(o[ps])]).all())
+        hb.close()
         out["end_to_end"] = {
             "value": round(sample * n / dt / 1e9, 3), "unit": "GB/s",
             "value_pinned": round(sample * n / dt_pin / 1e9, 3),
+            "value_pinned_persistent": round(ps * n / dt_hb / 1e9, 3),
+            "persistent_sample_chunks": ps,
+            "persistent_equals_device_path": same_as_device,
             "sample": f"m4g_find_matches_batch on the first {sample} chunks: workspace allocation + H2D + kernels + "
                       f"D2H of matches and histograms; `value` from pageable numpy memory (fresh output array), "
-                      f"`value_pinned` with input and output in m4g_host_alloc buffers",
+                      f"`value_pinned` with input and output in m4g_host_alloc buffers; `value_pinned_persistent`: "
+                      f"m4g_hostbatch_run on {ps} chunks from page-locked buffers, handle created beforehand "
+                      f"(H2D + kernels + D2H of matches and histograms, sliced and overlapped)",
         }
         pin_in.close()
         pin_out.close()

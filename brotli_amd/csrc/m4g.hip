@@ -1326,6 +1326,292 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
 }
 
 // ===========================================================================
+// persistent host-memory batch (include/m4g.h, m4g_hostbatch_*): the pipeline
+// of m4g_find_matches_batch with everything that call sets up and tears down
+// every time -- plans, device buffers, page-locked staging, streams, events --
+// created once, and one host thread per device.
+// ===========================================================================
+namespace {
+struct HostLane {
+  int device = 0;
+  size_t share = 0, slice = 0, nslices = 0; // capacity in chunks; chunks per slice; slices reserved
+  m4g_batch *plan = nullptr;
+  uint8_t *d_src = nullptr;
+  m4g_match *d_out = nullptr;
+  uint64_t *d_out_off = nullptr;
+  m4g_histo *d_histos = nullptr;
+  uint64_t *h_out_off = nullptr; // pinned, (slice + 1) per slice
+  uint32_t *h_err = nullptr;     // pinned, one word per slice
+  m4g_histo *h_histos = nullptr; // pinned staging (several devices: chunks interleave in the caller's array)
+  hipStream_t st_in = nullptr, st_run = nullptr, st_out = nullptr;
+  std::vector<hipEvent_t> ev_in, ev_run;
+  // per run
+  std::vector<size_t> chunks;         // global indices of this lane's chunks
+  std::vector<uint64_t> off, cap_off; // local input offsets / worst-case output slots
+  std::vector<uint64_t> count_off;    // local exclusive prefix of match counts (after phase 1)
+  int64_t result = M4G_OK;
+};
+} // namespace
+
+struct m4g_hostbatch {
+  Params p{};
+  m4g_params raw{};
+  size_t max_chunks = 0, max_chunk_bytes = 0;
+  std::vector<HostLane> lanes;
+};
+
+namespace {
+void hostlane_free(HostLane &L) {
+  (void)hipSetDevice(L.device);
+  for (hipStream_t st : {L.st_in, L.st_run, L.st_out})
+    if (st) (void)hipStreamSynchronize(st);
+  m4g_batch_destroy(L.plan);
+  (void)hipFree(L.d_src);
+  (void)hipFree(L.d_out);
+  (void)hipFree(L.d_out_off);
+  (void)hipFree(L.d_histos);
+  if (L.h_out_off) (void)hipHostFree(L.h_out_off);
+  if (L.h_err) (void)hipHostFree(L.h_err);
+  if (L.h_histos) (void)hipHostFree(L.h_histos);
+  for (auto &e : L.ev_in) if (e) (void)hipEventDestroy(e);
+  for (auto &e : L.ev_run) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t st : {L.st_in, L.st_run, L.st_out})
+    if (st) (void)hipStreamDestroy(st);
+  L = HostLane{};
+}
+
+#define LANE_TRY(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      L.result = fail(M4G_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+      return;                                                                            \
+    }                                                                                    \
+  } while (0)
+
+// Phase 1 of a run on one lane: every slice's upload (st_in) and kernels (st_run) are enqueued, then the
+// per-chunk match counts of all slices are awaited.  With one device the Match lists of a finished slice
+// start their way home (st_out) while later slices still compute: their place in `out` is already known.
+void hostlane_phase1(m4g_hostbatch *h, HostLane &L, size_t lane, const uint8_t *base, const uint64_t *chunk_off,
+                     size_t nchunks, m4g_match *out, uint64_t *out_off, size_t out_cap, bool want_histos) {
+  const size_t ndev = h->lanes.size();
+  L.result = M4G_OK;
+  L.chunks.clear();
+  for (size_t c = lane; c < nchunks; c += ndev) L.chunks.push_back(c);
+  const size_t n = L.chunks.size();
+  L.off.assign(n + 1, 0);
+  L.cap_off.assign(n + 1, 0);
+  L.count_off.assign(n + 1, 0);
+  for (size_t k = 0; k < n; k++) {
+    const uint64_t len = chunk_off[L.chunks[k] + 1] - chunk_off[L.chunks[k]];
+    L.off[k + 1] = L.off[k] + len;
+    L.cap_off[k + 1] = L.cap_off[k] + len / (size_t)h->p.min_length + 2;
+  }
+  if (n == 0) return;
+  LANE_TRY(hipSetDevice(L.device));
+  const size_t nsl = (n + L.slice - 1) / L.slice;
+  for (size_t s = 0; s < nsl; s++) {
+    const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice), nc = k1 - k0;
+    if (ndev == 1) { // the lane's chunks are one piece of the caller's buffer
+      if (L.off[k1] > L.off[k0])
+        LANE_TRY(hipMemcpyAsync(L.d_src + L.off[k0], base + chunk_off[k0], L.off[k1] - L.off[k0], hipMemcpyHostToDevice, L.st_in));
+    } else {
+      for (size_t k = k0; k < k1; k++)
+        if (L.off[k + 1] > L.off[k])
+          LANE_TRY(hipMemcpyAsync(L.d_src + L.off[k], base + chunk_off[L.chunks[k]], L.off[k + 1] - L.off[k],
+                                  hipMemcpyHostToDevice, L.st_in));
+    }
+    LANE_TRY(hipEventRecord(L.ev_in[s], L.st_in));
+    LANE_TRY(hipStreamWaitEvent(L.st_run, L.ev_in[s], 0));
+    const int rc = m4g_batch_run_device(L.plan, L.d_src, L.off.data() + k0, nc, L.d_out + L.cap_off[k0],
+                                        L.d_out_off + s * (L.slice + 1), L.cap_off[k1] - L.cap_off[k0],
+                                        want_histos ? L.d_histos + k0 : nullptr, L.st_run);
+    if (rc) {
+      L.result = rc;
+      return;
+    }
+    LANE_TRY(hipMemcpyAsync(L.h_out_off + s * (L.slice + 1), L.d_out_off + s * (L.slice + 1), (nc + 1) * 8,
+                            hipMemcpyDeviceToHost, L.st_run));
+    LANE_TRY(hipMemcpyAsync(L.h_err + s, L.plan->W.d_errors, 4, hipMemcpyDeviceToHost, L.st_run));
+    LANE_TRY(hipEventRecord(L.ev_run[s], L.st_run));
+  }
+  uint32_t err = 0;
+  uint64_t run = 0;
+  for (size_t s = 0; s < nsl; s++) {
+    const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice), nc = k1 - k0;
+    LANE_TRY(hipEventSynchronize(L.ev_run[s]));
+    err |= L.h_err[s];
+    const uint64_t *ho = L.h_out_off + s * (L.slice + 1);
+    for (size_t k = 0; k < nc; k++) L.count_off[k0 + k] = run + (ho[k] - ho[0]);
+    const uint64_t cnt = ho[nc] - ho[0];
+    if (ndev == 1) { // chunk order == local order: the slice's lists go to out[run ..) at once
+      for (size_t k = 0; k < nc; k++) out_off[k0 + k] = L.count_off[k0 + k];
+      if (!err && cnt && run + cnt <= out_cap)
+        LANE_TRY(hipMemcpyAsync(out + run, L.d_out + L.cap_off[k0] + ho[0], cnt * sizeof(m4g_match), hipMemcpyDeviceToHost, L.st_out));
+    }
+    run += cnt;
+  }
+  L.count_off[n] = run;
+  if (err) L.result = status_from_error_word(err);
+}
+
+// Phase 2 (several devices): the global offsets are known; every chunk's list goes to its place.
+void hostlane_phase2(m4g_hostbatch *h, HostLane &L, const uint64_t *out_off, m4g_match *out, m4g_histo *histos) {
+  const size_t n = L.chunks.size();
+  if (n == 0 || L.result != M4G_OK) return;
+  LANE_TRY(hipSetDevice(L.device));
+  const size_t nsl = (n + L.slice - 1) / L.slice;
+  for (size_t s = 0; s < nsl; s++) {
+    const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice);
+    const uint64_t *ho = L.h_out_off + s * (L.slice + 1);
+    for (size_t k = k0; k < k1; k++) {
+      const uint64_t cnt = ho[k - k0 + 1] - ho[k - k0];
+      if (cnt)
+        LANE_TRY(hipMemcpyAsync(out + out_off[L.chunks[k]], L.d_out + L.cap_off[k0] + ho[k - k0], cnt * sizeof(m4g_match),
+                                hipMemcpyDeviceToHost, L.st_out));
+    }
+  }
+  if (histos) {
+    LANE_TRY(hipMemcpyAsync(L.h_histos, L.d_histos, n * sizeof(m4g_histo), hipMemcpyDeviceToHost, L.st_out));
+    LANE_TRY(hipStreamSynchronize(L.st_out));
+    for (size_t k = 0; k < n; k++) histos[L.chunks[k]] = L.h_histos[k];
+  }
+  LANE_TRY(hipStreamSynchronize(L.st_out));
+  (void)h;
+}
+#undef LANE_TRY
+} // namespace
+
+extern "C" void m4g_hostbatch_destroy(m4g_hostbatch *h) {
+  if (!h) return;
+  for (auto &L : h->lanes) hostlane_free(L);
+  delete h;
+}
+
+extern "C" int m4g_hostbatch_create(const m4g_params *params, const int *devices, int ndevices, size_t max_chunks,
+                                    size_t max_chunk_bytes, m4g_hostbatch **out) {
+  if (!out) return fail(M4G_ERR_BAD_PARAM, "out is NULL");
+  *out = nullptr;
+  Params p;
+  int rc = resolve_params(params, &p);
+  if (rc) return rc;
+  if (!devices || ndevices < 1 || ndevices > 64) return fail(M4G_ERR_BAD_PARAM, "bad device list");
+  if (max_chunks == 0 || max_chunks > (1u << 24)) return fail(M4G_ERR_BAD_PARAM, "max_chunks out of range");
+  if (max_chunk_bytes == 0 || max_chunk_bytes > ((size_t)1 << 24))
+    return fail(M4G_ERR_TOO_LARGE, "max_chunk_bytes above 2^24 (largest brotli meta-block)");
+  for (int g = 0; g < ndevices; g++)
+    if ((rc = check_device(devices[g]))) return rc;
+  m4g_hostbatch *h = new m4g_hostbatch();
+  h->p = p;
+  h->raw = *params;
+  h->max_chunks = max_chunks;
+  h->max_chunk_bytes = max_chunk_bytes;
+  h->lanes.resize((size_t)ndevices);
+  for (int g = 0; g < ndevices; g++) {
+    HostLane &L = h->lanes[(size_t)g];
+    L.device = devices[g];
+    L.share = (max_chunks + (size_t)ndevices - 1) / (size_t)ndevices;
+    // slices: large enough to fill the GPU (>= 256 chunks), at most ~4 per run so that the copies of one
+    // overlap the kernels of the next (batch_one_device_pipelined has the measurements)
+    L.slice = std::max(kPipeSliceMin, (L.share + 3) / 4);
+    if (const char *e = std::getenv("M4G_PIPE_SLICE")) L.slice = std::max<size_t>(1, (size_t)std::atoll(e));
+    L.slice = std::min(L.slice, L.share);
+    L.nslices = (L.share + L.slice - 1) / L.slice;
+    const size_t cap = L.share * (max_chunk_bytes / (size_t)p.min_length + 2);
+    hipError_t e = hipSetDevice(L.device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.st_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.st_run, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.st_out, hipStreamNonBlocking);
+    if (e == hipSuccess && (rc = m4g_batch_create(params, L.device, L.slice, max_chunk_bytes, &L.plan))) {
+      m4g_hostbatch_destroy(h);
+      return rc;
+    }
+    if (e == hipSuccess) e = hipMalloc(&L.d_src, L.share * max_chunk_bytes + 64);
+    if (e == hipSuccess) e = hipMalloc(&L.d_out, cap * sizeof(m4g_match));
+    if (e == hipSuccess) e = hipMalloc(&L.d_out_off, L.nslices * (L.slice + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&L.d_histos, L.share * sizeof(m4g_histo));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&L.h_out_off), L.nslices * (L.slice + 1) * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&L.h_err), L.nslices * 4, hipHostMallocDefault);
+    if (e == hipSuccess && ndevices > 1)
+      e = hipHostMalloc(reinterpret_cast<void **>(&L.h_histos), L.share * sizeof(m4g_histo), hipHostMallocDefault);
+    L.ev_in.assign(L.nslices, nullptr);
+    L.ev_run.assign(L.nslices, nullptr);
+    for (size_t s = 0; s < L.nslices && e == hipSuccess; s++) {
+      e = hipEventCreateWithFlags(&L.ev_in[s], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev_run[s], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+      const std::string msg = std::string("m4g_hostbatch_create: ") + hipGetErrorString(e);
+      m4g_hostbatch_destroy(h);
+      return fail(e == hipErrorOutOfMemory ? M4G_ERR_NO_MEMORY : M4G_ERR_HIP, msg);
+    }
+  }
+  *out = h;
+  return M4G_OK;
+}
+
+extern "C" int64_t m4g_hostbatch_run(m4g_hostbatch *h, const uint8_t *base, const uint64_t *chunk_off, size_t nchunks,
+                                     m4g_match *out, uint64_t *out_off, size_t out_cap, m4g_histo *histos) {
+  if (!h || !chunk_off || !out_off || (!base && nchunks) || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (nchunks > h->max_chunks) return fail(M4G_ERR_TOO_LARGE, "nchunks above the handle's max_chunks");
+  out_off[0] = 0;
+  if (nchunks == 0) return M4G_OK;
+  for (size_t c = 0; c < nchunks; c++) {
+    if (chunk_off[c + 1] < chunk_off[c]) return fail(M4G_ERR_BAD_PARAM, "chunk_off not ascending");
+    if (chunk_off[c + 1] - chunk_off[c] > h->max_chunk_bytes)
+      return fail(M4G_ERR_TOO_LARGE, "chunk larger than the handle's max_chunk_bytes");
+  }
+  if (histos && h->p.min_length < 2)
+    return fail(M4G_ERR_BAD_PARAM, "histograms need MinLength >= 2 (brotli has no copy length code for 1)");
+  const size_t ndev = h->lanes.size();
+  // phase 1: one host thread per device
+  {
+    std::vector<std::thread> th;
+    for (size_t g = 1; g < ndev; g++)
+      th.emplace_back(hostlane_phase1, h, std::ref(h->lanes[g]), g, base, chunk_off, nchunks, out, out_off, out_cap, histos != nullptr);
+    hostlane_phase1(h, h->lanes[0], 0, base, chunk_off, nchunks, out, out_off, out_cap, histos != nullptr);
+    for (auto &t : th) t.join();
+  }
+  for (auto &L : h->lanes)
+    if (L.result != M4G_OK) { // (fail() text was set on the lane's thread: repeat it on the caller's)
+      for (auto &M : h->lanes) {
+        (void)hipSetDevice(M.device);
+        for (hipStream_t st : {M.st_in, M.st_run, M.st_out}) (void)hipStreamSynchronize(st);
+      }
+      return fail((int)L.result, "m4g_hostbatch_run: a device lane failed (kernel-side error or HIP error)");
+    }
+  if (ndev == 1) {
+    HostLane &L = h->lanes[0];
+    const uint64_t run = L.count_off[nchunks];
+    out_off[nchunks] = run;
+    HIP_TRY(hipSetDevice(L.device));
+    if (run <= out_cap && histos)
+      HIP_TRY(hipMemcpyAsync(histos, L.d_histos, nchunks * sizeof(m4g_histo), hipMemcpyDeviceToHost, L.st_out));
+    HIP_TRY(hipStreamSynchronize(L.st_out));
+    return run > out_cap ? -(int64_t)run : (int64_t)M4G_OK;
+  }
+  // several devices: global offsets in chunk order, then every lane sends its lists to their places
+  uint64_t run = 0;
+  for (size_t c = 0; c < nchunks; c++) {
+    const HostLane &L = h->lanes[c % ndev];
+    const size_t k = c / ndev;
+    out_off[c] = run;
+    run += L.count_off[k + 1] - L.count_off[k];
+  }
+  out_off[nchunks] = run;
+  if (run > out_cap) return -(int64_t)run;
+  {
+    std::vector<std::thread> th;
+    for (size_t g = 1; g < ndev; g++) th.emplace_back(hostlane_phase2, h, std::ref(h->lanes[g]), out_off, out, histos);
+    hostlane_phase2(h, h->lanes[0], out_off, out, histos);
+    for (auto &t : th) t.join();
+  }
+  for (auto &L : h->lanes)
+    if (L.result != M4G_OK) return fail((int)L.result, "m4g_hostbatch_run: copying the Match lists back failed");
+  return M4G_OK;
+}
+
+// ===========================================================================
 // streaming handle
 // ===========================================================================
 struct m4g_ctx {

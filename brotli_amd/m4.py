@@ -97,6 +97,11 @@ def lib():
         L.m4g_batch_set_timing.argtypes = [vp, ctypes.c_int]
         L.m4g_batch_set_timing.restype = None
         L.m4g_batch_status.argtypes = [vp]
+        L.m4g_hostbatch_create.argtypes = [ctypes.POINTER(Params), vp, ctypes.c_int, sz, sz, ctypes.POINTER(vp)]
+        L.m4g_hostbatch_run.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
+        L.m4g_hostbatch_run.restype = ctypes.c_int64
+        L.m4g_hostbatch_destroy.argtypes = [vp]
+        L.m4g_hostbatch_destroy.restype = None
         L.m4g_batch_encode.argtypes = [vp, vp, sz, vp, vp, vp, vp, ctypes.c_int, vp, sz, vp,
                                        ctypes.POINTER(ctypes.c_float)]
         L.m4g_batch_encode.restype = ctypes.c_int64
@@ -434,6 +439,50 @@ class PinnedBuffer:
             self.close()
         except Exception:
             pass
+
+
+class HostBatch:
+    """m4g_hostbatch_*: find_matches_batch on a persistent handle (plans, device
+    buffers, pinned staging and streams created once; one host thread per device)."""
+
+    def __init__(self, max_chunks: int, max_chunk_bytes: int, devices: Sequence[int] = (0,), **m4_fields):
+        self.params = _params(m4_fields.get("MaxDistance", 0), m4_fields.get("MinLength", 0),
+                              m4_fields.get("HashLen", 0), m4_fields.get("TableBits", 0),
+                              m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        _check(lib().m4g_hostbatch_create(ctypes.byref(self.params), devs, len(devices), max_chunks,
+                                          max_chunk_bytes, ctypes.byref(h)), "m4g_hostbatch_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().m4g_hostbatch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def run(self, base, chunk_off: Sequence[int], want_histos: bool = False, out: "np.ndarray | None" = None):
+        """Returns (matches[M,3], out_off[nchunks+1], histos or None), as find_matches_batch."""
+        a = _as_u8(base)
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        n = off.size - 1
+        min_len = self.params.min_length or 4
+        if out is None:
+            cap = int(sum(int(off[c + 1] - off[c]) // min_len + 2 for c in range(n))) + 1
+            out = np.empty((cap, 3), dtype=np.uint32)
+        else:
+            assert out.dtype == np.uint32 and out.flags.c_contiguous
+            out = out.reshape(-1)[:out.size // 3 * 3].reshape(-1, 3)
+            cap = out.shape[0]
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        histos = np.zeros((max(n, 1), 1024), dtype=np.uint32) if want_histos else None
+        r = lib().m4g_hostbatch_run(self._h, a.ctypes.data if a.size else None, off.ctypes.data, n, out.ctypes.data,
+                                    out_off.ctypes.data, cap, histos.ctypes.data if want_histos else None)
+        _check(r, "m4g_hostbatch_run")
+        if r < 0:
+            raise M4GError(f"m4g_hostbatch_run: out_cap too small, need {-r}")
+        return out[:int(out_off[n])], out_off, (histos[:n] if want_histos else None)
 
 
 def find_matches_batch(base, chunk_off: Sequence[int], devices: Sequence[int] = (0,),

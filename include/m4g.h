@@ -209,6 +209,24 @@ int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
                                uint64_t *out_off, size_t out_cap,
                                m4g_histo *histos);
 
+/* The same call on a persistent handle: plans, device buffers, page-locked
+ * staging, streams and events are created ONCE for up to max_chunks chunks of
+ * up to max_chunk_bytes bytes over the listed devices (chunk c on
+ * devices[c % ndevices], one host thread per device), so a run pays for copies
+ * and kernels only -- m4g_find_matches_batch allocates and frees all of it on
+ * every call (tens of GiB of workspace for a few thousand chunks).  One
+ * device: the batch is cut into slices whose upload, kernels and download
+ * overlap.  Semantics, results and return values as m4g_find_matches_batch.
+ * One thread at a time per handle.  No counterpart in the reference beyond the
+ * per-chunk semantics cited above (AutoReset + Encoder pass 1). */
+typedef struct m4g_hostbatch m4g_hostbatch;
+int m4g_hostbatch_create(const m4g_params *params, const int *devices, int ndevices,
+                         size_t max_chunks, size_t max_chunk_bytes, m4g_hostbatch **out);
+int64_t m4g_hostbatch_run(m4g_hostbatch *h, const uint8_t *base, const uint64_t *chunk_off,
+                          size_t nchunks, m4g_match *out, uint64_t *out_off, size_t out_cap,
+                          m4g_histo *histos);
+void m4g_hostbatch_destroy(m4g_hostbatch *h);
+
 /* Replaces: brotli.Encoder.Encode(dst, chunk, matches, false) called for every
  * chunk of the batch in chunk order on ONE Encoder (encoder.go:17-161), i.e.
  * what matchfinder.Writer does after FindMatches (matchfinder.go:84) -- the

@@ -223,6 +223,31 @@ def test_batch_host_api_sharded_over_device_list():
         assert same(three[0][int(three[1][c]):int(three[1][c + 1])], ref), f"chunk {c}"
 
 
+@pytest.mark.parametrize("devices", [(0,), (0, 0, 0)], ids=["one_device", "three_lanes"])
+def test_persistent_host_batch(devices):
+    """m4g_hostbatch_*: same results as m4g_find_matches_batch (and the oracle), over
+    several runs of changing shape on one handle; the (0, 0, 0) device list runs the
+    several-devices code (per-chunk copies, ordered concatenation, one thread per lane)."""
+    hb = m4.HostBatch(700, 1 << 16, devices, **PARAMS_G)
+    rng = np.random.default_rng(11)
+    for rounds, nchunks in enumerate((600, 7, 0, 1, 700)):
+        lens = rng.integers(0, (1 << 16) + 1, nchunks)
+        if nchunks > 3:
+            lens[1] = 0
+            lens[2] = 1 << 16
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        base = np.frombuffer(synth.text(int(off[-1]) + 1, 100 + rounds), dtype=np.uint8)[:int(off[-1])]
+        got, goff, gh = hb.run(base, off, want_histos=True)
+        ref, roff, rh = m4.find_matches_batch(base, off, (0,), True, **PARAMS_G)
+        assert (goff == roff).all() and same(got, ref)
+        if nchunks:
+            assert (gh == rh).all()
+        for c in list(range(min(nchunks, 4))) + ([nchunks - 1] if nchunks else []):
+            chunk = base[int(off[c]):int(off[c + 1])]
+            assert same(got[int(goff[c]):int(goff[c + 1])], OracleM4(**PARAMS_G).FindMatches(chunk)), c
+    hb.close()
+
+
 def test_batch_inputs_that_defeat_the_speculation():
     """Inputs on which the sub-block speculation cannot synchronise through a
     common flush: incompressible bytes (no matches at all), zero pages and short
