@@ -47,6 +47,7 @@ constexpr int KP_CSTRIDE = KP_BINS + 1;             // odd stride: a wave's coun
 #endif
 constexpr int KP_TPW = M4G_KP_TPW;                         // tiles per k1p workgroup (consecutive, one job)
 constexpr int KP_KEY_IDX_SHIFT = 17;                // key = index in the owner's slice << 17 | rel << cb | check bits
+constexpr uint32_t KP_KEY_SET_ONLY = 0x80000000u;   // key flag: exchange, but the chain entry is already stored
 constexpr uint32_t KP_EMPTY = 0xFFFFFFFFu;          // tile image word without a chain entry (no entry has this value)
 static_assert(KP_TILE <= 4096, "tile position must fit the key");
 
@@ -60,8 +61,8 @@ static_assert(k1c_lds_bytes(15) <= 160 * 1024, "LDS of one CU");
 
 __global__ __launch_bounds__(KP_THREADS, 8) void k1p_partition(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ keys_base,
-    uint32_t *__restrict__ hdr_base, const Job *__restrict__ jobs, int njobs, uint32_t kt_max,
-    uint32_t groups_per_job, int hash_len, int table_bits, int bin_bits, int check_bits) {
+    uint32_t *__restrict__ hdr_base, uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, int njobs,
+    uint32_t kt_max, uint32_t groups_per_job, int hash_len, int table_bits, int bin_bits, int check_bits) {
   __shared__ uint32_t cnt[16 * KP_CSTRIDE]; // [wave][bin]: keys of the wave in the bin, then their first slot
   __shared__ uint32_t tot[KP_BINS];
   __shared__ uint32_t stage[KP_TILE];
@@ -127,6 +128,22 @@ __global__ __launch_bounds__(KP_THREADS, 8) void k1p_partition(
       key[j] = ((h & slice_mask) << KP_KEY_IDX_SHIFT) | (rel << cb) | ck;
       bin[j] = rel < lim ? (h >> slice_bits) : KP_BINS; // KP_BINS: no key
       rank[j] = 0;
+      // Runs of neighbouring positions with one hash (zero padding, constant fills) inside this row of 64:
+      // every member but the first has its left neighbour as predecessor, so its chain entry is known here
+      // and is stored here; the table only has to see the first member (a normal key: it looks the entry
+      // up) and the last one (a KP_KEY_SET_ONLY key: it leaves its position there).  A page of zeros
+      // becomes 2 keys per row instead of 64, all of them in one bin.
+      {
+        const uint32_t hv = rel < lim ? h : 0x80000000u | lane; // no key: equal to nobody
+        const uint32_t ph = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)hv, 0x138, 0xf, 0xf, false); // wave_shr:1
+        const uint32_t pck = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ck, 0x138, 0xf, 0xf, false);
+        const uint32_t nh = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)hv, 0x130, 0xf, 0xf, false); // wave_shl:1
+        if (hv == ph) { // (position sb + rel >= 1 here; a predecessor at position 0 counts as "empty", m4.go:152)
+          chain_base[J.chain_off + sb + rel] = sb + rel > 1 ? (1u | (pck == ck ? kChainMaybe : 0u)) : 0u;
+          if (hv == nh) bin[j] = KP_BINS;
+          else key[j] |= KP_KEY_SET_ONLY;
+        }
+      }
       // rows in program order, lanes of a row in ascending order: rank = position order inside (wave, bin)
       if (bin[j] < KP_BINS)
         rank[j] = __hip_atomic_fetch_add(&mycnt[bin[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -253,9 +270,9 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_scatter(
       {
         const bool act = lane < n;
         const uint32_t val = vbase + (k[u] & low_mask);
-        uint32_t *p = act ? slice + (k[u] >> KP_KEY_IDX_SHIFT) : dummy;
+        uint32_t *p = act ? slice + ((k[u] & ~KP_KEY_SET_ONLY) >> KP_KEY_IDX_SHIFT) : dummy;
         const uint32_t old = __hip_atomic_exchange(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (act) chain[val >> cb] = entry(val, old);
+        if (act && !(k[u] & KP_KEY_SET_ONLY)) chain[val >> cb] = entry(val, old);
       }
       if (n > 64) { // a crowded bin (zero pages, short periods): the rest in groups of KS_X batches
         const uint32_t *kp = keys + sb + (h[u] >> 16);
@@ -270,9 +287,9 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_scatter(
           for (uint32_t v = 0; v < KS_X; v++) {
             const bool act = e0 + v * 64 + lane < n;
             const uint32_t val = vbase + (kk[v] & low_mask);
-            uint32_t *p = act ? slice + (kk[v] >> KP_KEY_IDX_SHIFT) : dummy;
+            uint32_t *p = act ? slice + ((kk[v] & ~KP_KEY_SET_ONLY) >> KP_KEY_IDX_SHIFT) : dummy;
             const uint32_t old = __hip_atomic_exchange(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (act) chain[val >> cb] = entry(val, old);
+            if (act && !(kk[v] & KP_KEY_SET_ONLY)) chain[val >> cb] = entry(val, old);
           }
         }
       }
@@ -280,15 +297,23 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_scatter(
   }
 }
 
-// The loads of a wave are software-pipelined in steps of KC_G tiles: while step s
-// is processed, the first 64 keys of the wave's bin in every tile of step s+1 and
-// the headers of step s+2 are in flight.  Loads are issued back to back and
-// pinned with empty asm statements -- the compiler otherwise sinks each load into
-// the branch that uses it and waits for it there, one memory round trip per tile.
+// Loads of a wave, all software-pipelined (a wave that waits for memory holds up the 15 others at the tile's
+// barrier):
+//   * headers: ONE load per 64 tiles, lane = tile; a tile's header is then a v_readlane (scalar), two blocks
+//     of 64 tiles ahead;
+//   * the first 128 keys of the wave's bin in every tile, in steps of KC_G tiles, one step ahead (a bin of
+//     text holds 48 keys on average and more than 64 in one tile out of six for some wave of the workgroup);
+//   * keys 128 .. 128 + 64 * KC_X of a crowded bin (log records: ~900 of a tile's 3072 positions share one
+//     hash; zero pages, short periods), one tile ahead into one of two register buffers; whatever lies
+//     beyond that is loaded on the spot.
+// Loads are issued back to back and pinned with empty asm statements -- the compiler otherwise sinks each load
+// into the branch that uses it and waits for it there, one memory round trip per tile.
 #ifndef M4G_KC_G
-#define M4G_KC_G 16
+#define M4G_KC_G 8
 #endif
-constexpr uint32_t KC_G = M4G_KC_G;
+constexpr uint32_t KC_G = M4G_KC_G; // tiles per load step
+constexpr uint32_t KC_X = 16;       // batches of 64 keys per extras buffer
+static_assert(64 % KC_G == 0 && KC_G % 2 == 0, "steps tile a header block; the extras buffers alternate by tile parity");
 __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
     const uint32_t *__restrict__ keys_base, const uint32_t *__restrict__ hdr_base,
     uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, int njobs, uint32_t kt_max,
@@ -320,9 +345,7 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
   const uint32_t slice_bits = (uint32_t)part_bits - 4;
   uint32_t *slice = table + (wave << slice_bits);
   uint32_t *dummy = res + 2 * KP_TILE + tid; // where the exchange of a lane without a key goes
-  uint32_t vz = 0;
-  asm volatile("" : "+v"(vz)); // a zero the compiler cannot see through: keeps the header loads vector loads
-  const uint32_t *hp = hdr_base + (uint64_t)job * kt_max * KP_BINS + q * 16 + wave + vz; // + t * KP_BINS
+  const uint32_t *hp = hdr_base + (uint64_t)job * kt_max * KP_BINS + q * 16 + wave; // + t * KP_BINS
   const uint32_t *keys = keys_base + J.chain_off;
   uint32_t *chain = chain_base + J.chain_off;
   const uint32_t low_mask = (1u << KP_KEY_IDX_SHIFT) - 1;
@@ -332,32 +355,51 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
     const uint32_t pos = val >> cb, pp = old >> cb;
     return pp > 0 ? ((pos - pp) | ((old & cmask) == (val & cmask) ? kChainMaybe : 0u)) : 0u;
   };
-  // headers / keys of the KC_G tiles from tb on (tiles past the end re-read the last one; masked at use)
-  auto load_hdrs = [&](uint32_t tb, uint32_t *h) {
-#pragma unroll
-    for (uint32_t u = 0; u < KC_G; u++) h[u] = hp[(uint64_t)min(tb + u, ntiles - 1) * KP_BINS];
+  // headers of the 64 tiles from T0 on, lane = tile (tiles past the end repeat the last one; masked at use)
+  auto load_hv = [&](uint32_t T0) -> uint32_t { return hp[(uint64_t)min(T0 + lane, ntiles - 1) * KP_BINS]; };
+  uint32_t hv = load_hv(0), hvn = load_hv(64), hvnn = load_hv(128);
+  // header of tile (first tile of the current block) + i, i < 128, as a scalar
+  auto hdr_at = [&](uint32_t i) -> uint32_t {
+    return i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)hv, (int)i)
+                  : (uint32_t)__builtin_amdgcn_readlane((int)hvn, (int)(i - 64));
   };
-  auto load_keys = [&](uint32_t tb, const uint32_t *h, uint32_t *k) {
+  // keys 0 .. 127 of the wave's bin in the KC_G tiles from tb on (= block tile i0 on); lanes past the bin
+  // read on into the next bins (the key buffer ends with a margin): unused
+  auto load_keys = [&](uint32_t tb, uint32_t i0, uint32_t *k, uint32_t *kb) {
 #pragma unroll
-    for (uint32_t u = 0; u < KC_G; u++) // lanes past the bin read a few words on: unused
-      k[u] = keys[(uint64_t)min(tb + u, ntiles - 1) * KP_TILE + (h[u] >> 16) + lane];
+    for (uint32_t u = 0; u < KC_G; u++) {
+      const uint32_t *kp = keys + (uint64_t)min(tb + u, ntiles - 1) * KP_TILE + (hdr_at(i0 + u) >> 16);
+      k[u] = kp[lane];
+      kb[u] = kp[64 + lane];
+    }
   };
-  auto pin = [&](uint32_t *v) {
+  auto load_extra = [&](uint32_t t, uint32_t h, uint32_t e0, uint32_t *kx) {
+    const uint32_t n = h & 0xFFFFu;
+    const uint32_t *kp = keys + (uint64_t)t * KP_TILE + (h >> 16);
 #pragma unroll
-    for (uint32_t u = 0; u < KC_G; u++) asm volatile("" : "+v"(v[u]));
+    for (uint32_t v = 0; v < KC_X; v++) kx[v] = kp[min(e0 + v * 64 + lane, n - 1)];
+  };
+  auto pin = [&](uint32_t *v, uint32_t cnt) {
+#pragma unroll
+    for (uint32_t u = 0; u < cnt; u++) asm volatile("" : "+v"(v[u]));
   };
 
-  uint32_t h0[KC_G], h1[KC_G], h2[KC_G], k0[KC_G], k1[KC_G];
-  load_hdrs(0, h0);
-  load_hdrs(KC_G, h1);
-  pin(h0);
-  load_keys(0, h0, k0);
+  uint32_t k0[KC_G], k0b[KC_G], k1[KC_G], k1b[KC_G], xa[KC_X], xb[KC_X];
+  load_keys(0, 0, k0, k0b);
+#pragma unroll
+  for (uint32_t v = 0; v < KC_X; v++) xa[v] = xb[v] = 0;
+  {
+    const uint32_t h = hdr_at(0);
+    if ((h & 0xFFFFu) > 128) load_extra(0, h, 128, xa);
+  }
   lds_barrier(); // table and images initialised
 
   // The store phase of tile t-1 runs inside iteration t, around the exchanges of tile t: one barrier per
   // tile, and the LDS round trips of the two halves overlap within a wave.
   // Barrier at the top of iteration t: image (t-1) & 1 is complete (every wave has finished tile t-1), and
   // image t & 1 has been emptied again (its words were stored and reset during iteration t-1).
+  // NEVER remove that barrier, not even in a timing experiment: without it a wave stores stale image words
+  // with a later tile's base, beyond the end of the chain array.
   auto store_tile = [&](const uint32_t *ent, uint32_t *img, uint32_t sb) {
     // every wave stores 64 consecutive positions per instruction; only this partition's words are set
 #pragma unroll
@@ -370,59 +412,90 @@ __global__ __launch_bounds__(KP_THREADS) void k1c_consume(
     }
   };
 #pragma unroll 1
-  for (uint32_t tb = 0; tb < ntiles; tb += KC_G) {
-    pin(k0); // requested one step ago
-    pin(h1);
-    load_hdrs(tb + 2 * KC_G, h2);
-    load_keys(tb + KC_G, h1, k1);
-#pragma unroll
-    for (uint32_t u = 0; u < KC_G; u++) {
-      const uint32_t t = tb + u;
-      if (t >= ntiles) break; // workgroup-uniform
-      const uint32_t sb = t * KP_TILE;
-      uint32_t *img = res + (t & 1) * KP_TILE, *imgp = res + ((t & 1) ^ 1) * KP_TILE;
-      uint32_t ent[KP_ROWS];
-      if (t > 0) lds_barrier();
-#pragma unroll
-      for (int j = 0; j < KP_ROWS; j++) ent[j] = t > 0 ? imgp[j * KP_THREADS + tid] : KP_EMPTY;
-      const uint32_t n = h0[u] & 0xFFFFu;
-      const uint32_t vbase = sb << cb; // table value = vbase + low key bits = position << cb | check bits
-      {
-        const bool act = lane < n;
-        const uint32_t low = k0[u] & low_mask, val = vbase + low;
-        uint32_t *p = act ? slice + (k0[u] >> KP_KEY_IDX_SHIFT) : dummy;
-        const uint32_t old = __hip_atomic_exchange(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        uint32_t *ip = act ? img + (low >> cb) : dummy;
-        *ip = entry(val, old);
-      }
-      if (n > 64) { // a crowded bin (zero pages, short periods): the rest in groups of 8 batches
-        const uint32_t *kp = keys + sb + (h0[u] >> 16);
+  for (uint32_t T0 = 0; T0 < ntiles; T0 += 64) {
 #pragma unroll 1
-        for (uint32_t e0 = 64; e0 < n; e0 += 64 * 8) {
-          uint32_t kk[8];
+    for (uint32_t s = 0; s < 64 / KC_G; s++) {
+      const uint32_t tb = T0 + s * KC_G;
+      if (tb >= ntiles) break;
+      pin(k0, KC_G); // requested one step ago
+      pin(k0b, KC_G);
+      load_keys(tb + KC_G, s * KC_G + KC_G, k1, k1b);
 #pragma unroll
-          for (uint32_t v = 0; v < 8; v++) kk[v] = kp[min(e0 + v * 64 + lane, n - 1)];
+      for (uint32_t u = 0; u < KC_G; u++) {
+        const uint32_t t = tb + u;
+        if (t >= ntiles) break; // workgroup-uniform
+        const uint32_t sb = t * KP_TILE;
+        uint32_t *img = res + (t & 1) * KP_TILE, *imgp = res + ((t & 1) ^ 1) * KP_TILE;
+        uint32_t *cur = (u & 1) ? xb : xa, *nxt = (u & 1) ? xa : xb; // extras of this tile / of the next one
+        const uint32_t h = hdr_at(s * KC_G + u), n = h & 0xFFFFu;
+        const uint32_t *kp = keys + sb + (h >> 16);
+        if (n > 128) pin(cur, KC_X); // requested one tile ago; waited for BEFORE the next request goes out
+        {
+          const uint32_t hn = hdr_at(s * KC_G + u + 1);
+          if (t + 1 < ntiles && (hn & 0xFFFFu) > 128) load_extra(t + 1, hn, 128, nxt);
+        }
+        uint32_t ent[KP_ROWS];
+        if (t > 0) lds_barrier();
 #pragma unroll
-          for (uint32_t v = 0; v < 8; v++) asm volatile("" : "+v"(kk[v]));
+        for (int j = 0; j < KP_ROWS; j++) ent[j] = t > 0 ? imgp[j * KP_THREADS + tid] : KP_EMPTY;
+        const uint32_t vbase = sb << cb; // table value = vbase + low key bits = position << cb | check bits
+        {
+          const bool act = lane < n;
+          const uint32_t low = k0[u] & low_mask, val = vbase + low;
+          uint32_t *p = act ? slice + ((k0[u] & ~KP_KEY_SET_ONLY) >> KP_KEY_IDX_SHIFT) : dummy;
+          const uint32_t old = __hip_atomic_exchange(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          uint32_t *ip = act && !(k0[u] & KP_KEY_SET_ONLY) ? img + (low >> cb) : dummy;
+          *ip = entry(val, old);
+        }
+        if (n > 64) {
+          // Runs of neighbouring keys with the same table entry are folded: 64 lanes exchanging on ONE
+          // address are performed one after the other.  Inside a run every key's predecessor is its left
+          // neighbour; the run's first lane alone goes to the table, leaves the run's LAST value there and
+          // takes the old one.
+          auto batch = [&](uint32_t key, uint32_t e0) {
+            const bool act = e0 + lane < n;
+            const uint32_t low = key & low_mask, val = vbase + low;
+            const uint32_t idx = act ? (key & ~KP_KEY_SET_ONLY) >> KP_KEY_IDX_SHIFT : 0x10000u | lane; // no key: equal to nobody
+            const uint32_t pidx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)idx, 0x138, 0xf, 0xf, false); // wave_shr:1
+            const uint32_t pval = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)val, 0x138, 0xf, 0xf, false);
+            const uint32_t nidx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)idx, 0x130, 0xf, 0xf, false); // wave_shl:1
+            const bool cont = idx == pidx;
+            const unsigned long long tails = __ballot(idx != nidx); // lane 63 is always one
+            const uint32_t tl = lane + (uint32_t)__builtin_ctzll(tails >> lane);
+            const uint32_t tval = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tl << 2), (int)val);
+            uint32_t *p = act && !cont ? slice + idx : dummy;
+            const uint32_t old = __hip_atomic_exchange(p, tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t *ip = act && !(key & KP_KEY_SET_ONLY) ? img + (low >> cb) : dummy;
+            *ip = entry(val, cont ? pval : old);
+          };
+          batch(k0b[u], 64);
+          uint32_t e = 128;
+          while (e < n) {
+#pragma unroll 1
+            for (uint32_t v = 0; v < KC_X && e < n; v++, e += 64) {
+              batch(cur[0], e);
 #pragma unroll
-          for (uint32_t v = 0; v < 8; v++) {
-            const bool act = e0 + v * 64 + lane < n;
-            const uint32_t low = kk[v] & low_mask, val = vbase + low;
-            uint32_t *p = act ? slice + (kk[v] >> KP_KEY_IDX_SHIFT) : dummy;
-            const uint32_t old = __hip_atomic_exchange(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            uint32_t *ip = act ? img + (low >> cb) : dummy;
-            *ip = entry(val, old);
+              for (uint32_t w = 0; w + 1 < KC_X; w++) cur[w] = cur[w + 1];
+            }
+            if (e < n) { // more than 128 + 64 * KC_X keys (zero pages): on the spot
+              load_extra(t, h, e, cur);
+              pin(cur, KC_X);
+            }
           }
         }
+        store_tile(ent, imgp, sb - KP_TILE); // (nothing in iteration 0: every word is KP_EMPTY)
+        (void)kp;
       }
-      store_tile(ent, imgp, sb - KP_TILE); // (nothing in iteration 0: every word is KP_EMPTY)
-    }
 #pragma unroll
-    for (uint32_t u = 0; u < KC_G; u++) {
-      h0[u] = h1[u];
-      h1[u] = h2[u];
-      k0[u] = k1[u];
+      for (uint32_t u = 0; u < KC_G; u++) {
+        k0[u] = k1[u];
+        k0b[u] = k1b[u];
+      }
     }
+    hv = hvn;
+    asm volatile("" : "+v"(hvnn)); // requested a block ago
+    hvn = hvnn;
+    hvnn = load_hv(T0 + 192);
   }
   lds_barrier(); // the image of the last tile is complete
   {

@@ -259,7 +259,7 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
     const uint32_t gpj = (split->kt_max + KP_TPW - 1) / KP_TPW;
     const int bin_bits = (p.table_bits - pb) + 4;
     hipLaunchKernelGGL(k1p_partition, dim3((unsigned)njobs * gpj), dim3(KP_THREADS), 0, st, d_src, src_total,
-                       split->keys, split->hdr, d_jobs, njobs, split->kt_max, gpj, p.hash_len, p.table_bits, bin_bits, cb);
+                       split->keys, split->hdr, d_chain, d_jobs, njobs, split->kt_max, gpj, p.hash_len, p.table_bits, bin_bits, cb);
     HIP_TRY(hipGetLastError());
     static const bool image = std::getenv("M4G_K1C_SCATTER") == nullptr;
     if (image)
@@ -494,7 +494,7 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
     b->W.split.kt_max = kp_tiles((uint32_t)max_chunk_bytes);
     if (p.table_bits >= 4 && p.table_bits <= kMaxPartBits + 2 && b->W.split.kt_max > 0) {
       const size_t rs_bytes = b->W.w.blocks * b->W.w.L.slot * sizeof(Rec);
-      if (rs_bytes >= chain_bytes) {
+      if (rs_bytes >= chain_bytes + 4096) { // (k1c reads up to 127 words past a bin)
         b->W.split.keys = reinterpret_cast<uint32_t *>(b->W.w.rs);
       } else if ((e = hipMalloc(&b->W.keys_own, chain_bytes + 4096)) == hipSuccess) {
         b->W.split.keys = b->W.keys_own;

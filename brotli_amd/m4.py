@@ -39,6 +39,7 @@ EXPORTS = [
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
     "m4g_batch_status", "m4g_batch_run_device_noalloc",
+    "m4g_batch_encode", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
 ]
 
 _LIB = None
