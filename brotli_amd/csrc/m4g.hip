@@ -297,7 +297,9 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
   const ParseParams P = parse_params(p);
   const uint64_t lanes = (uint64_t)njobs * w.L.kmax;
   const unsigned g3 = (unsigned)((lanes + K3_THREADS - 1) / K3_THREADS);
-  hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), 0, st, d_src, src_total, d_chain, d_jobs,
+  // tuning aid: unused dynamic LDS per workgroup = fewer waves per CU = fewer chunks in flight per XCD
+  static const unsigned k3a_pad = std::getenv("M4G_K3A_LDS_PAD") ? (unsigned)std::atoi(std::getenv("M4G_K3A_LDS_PAD")) : 0u;
+  hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
                      w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
   HIP_TRY(hipGetLastError());
   if (w.L.kmax > 1) {
