@@ -64,6 +64,26 @@ def lib():
         L.encref_copy_length_code.restype = ctypes.c_uint16
         L.encref_combine_length_codes.argtypes = [ctypes.c_uint16, ctypes.c_uint16, ctypes.c_int]
         L.encref_combine_length_codes.restype = ctypes.c_uint16
+        # flate / gzip encoders (oracle/flate_ref.c)
+        L.flateref_length_code.argtypes = [ctypes.c_uint32]
+        L.flateref_offset_code.argtypes = [ctypes.c_uint32]
+        L.flateref_generate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.flateref_statistics.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+        L.flateref_encoder_new.argtypes = [ctypes.c_int, ctypes.c_uint32]
+        L.flateref_encoder_new.restype = ctypes.c_void_p
+        L.flateref_encoder_free.argtypes = [ctypes.c_void_p]
+        L.flateref_encoder_reset.argtypes = [ctypes.c_void_p]
+        L.flateref_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.flateref_encoder_take.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        L.flateref_encoder_take.restype = ctypes.c_void_p
+        L.flateref_compress_m4.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                           ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t)]
+        L.flateref_compress_m4.restype = ctypes.c_void_p
+        L.flateref_free_buf.argtypes = [ctypes.c_void_p]
+        L.flateref_crc32.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+        L.flateref_crc32.restype = ctypes.c_uint32
         _LIB = L
     return _LIB
 
@@ -132,6 +152,76 @@ class OracleM4:
         out = ctypes.string_at(p, osz.value)
         lib().encref_free_buf(p)
         return out, nm.value
+
+
+def flate_m4_params(level: int) -> dict:
+    """flate.newWriter's match finder for the levels that use matchfinder.M4 (flate/writer.go:33-46)."""
+    if not 5 <= level <= 7:
+        raise ValueError("flate levels 5..7 use matchfinder.M4")
+    return dict(MaxDistance=1 << 15, ChainLength={5: 8, 6: 16, 7: 32}[level], HashLen=5, DistanceBitCost=66)
+
+
+class OracleFlateEncoder:
+    """flate.NewEncoder() / flate.NewGZIPEncoder() restated (oracle/flate_ref.c)."""
+
+    KINDS = ("stored", "fixed", "dynamic")
+
+    def __init__(self, gzip: bool = False, mtime: int = 0):
+        self._h = lib().flateref_encoder_new(1 if gzip else 0, mtime)
+        self.last_kind = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().flateref_encoder_free(self._h)
+            self._h = None
+
+    def Reset(self):
+        lib().flateref_encoder_reset(self._h)
+
+    def Encode(self, src, matches: np.ndarray, last_block: bool, nil_src: bool = False) -> bytes:
+        addr, n, keep = _buf(src)
+        m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 3)
+        kind = ctypes.c_int(-1)
+        rc = lib().flateref_encode(self._h, addr, n, 1 if nil_src else 0, m.ctypes.data if len(m) else None, len(m),
+                                   1 if last_block else 0, ctypes.byref(kind))
+        if rc:
+            raise ValueError("flate: match too long or distance too high (the reference panics, token.go:59-71)")
+        self.last_kind = self.KINDS[kind.value]
+        sz = ctypes.c_size_t()
+        p = lib().flateref_encoder_take(self._h, ctypes.byref(sz))
+        return ctypes.string_at(p, sz.value) if sz.value else b""
+
+
+def flate_compress(m4: "OracleM4", data, block_size: int = 1 << 16, gzip: bool = False, mtime: int = 0) -> bytes:
+    """matchfinder.Writer{M4, flate encoder, BlockSize}: Write(data); Close()."""
+    addr, n, keep = _buf(data)
+    osz = ctypes.c_size_t()
+    p = lib().flateref_compress_m4(m4._h, addr, n, block_size, 1 if gzip else 0, mtime, ctypes.byref(osz))
+    if not p:
+        raise ValueError("flate: match too long or distance too high (the reference panics)")
+    out = ctypes.string_at(p, osz.value)
+    lib().flateref_free_buf(p)
+    return out
+
+
+def flate_statistics(src, matches: np.ndarray):
+    """makeStatistics' frequencies (huffman_bit_writer.go:425-446): (lit[286], off[30]) as int32."""
+    addr, n, keep = _buf(src)
+    m = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 3)
+    lit = np.zeros(286, dtype=np.int32)
+    off = np.zeros(30, dtype=np.int32)
+    if lib().flateref_statistics(addr, n, m.ctypes.data if len(m) else None, len(m), lit.ctypes.data, off.ctypes.data):
+        raise ValueError("flate: match too long or distance too high")
+    return lit, off
+
+
+def flate_generate(freq, max_bits: int):
+    """huffmanEncoder.generate (huffman_code.go:271-309): (codes, lengths) as uint16."""
+    f = np.ascontiguousarray(freq, dtype=np.int32)
+    code = np.zeros(len(f), dtype=np.uint16)
+    ln = np.zeros(len(f), dtype=np.uint16)
+    lib().flateref_generate(f.ctypes.data, len(f), max_bits, code.ctypes.data, ln.ctypes.data)
+    return code, ln
 
 
 def histograms(src, matches: np.ndarray):
