@@ -122,6 +122,65 @@ def pmc_traffic(kernel: str, args, input_bytes: int):
     return None if per_byte is None else round(per_byte * input_bytes / 1e9, 3)
 
 
+def flate_leg(host, n: int, chunks: int, dev, device_index: int, no_cpu: bool) -> dict:
+    """flate.NewGZIPWriter(level 6) over `chunks` chunks (one deflate block per chunk, fresh M4 per chunk): match
+    finding at the level's M4 parameters (flate/writer.go:33-46) and the gzip encoder on the GPU
+    (m4g_batch_flate_encode).  Reported beside `value`; checked by inflating the whole stream."""
+    import gzip
+    import numpy as np
+    import torch
+    from brotli_amd import m4
+    kw = m4.flate_m4_params(6)
+    try:
+        plan = m4.BatchPlan(chunks, n, device_index, **kw)
+        plan.set_timing(True)
+        off = np.arange(chunks + 1, dtype=np.uint64) * n
+        d_src = torch.empty(n * chunks + 64, dtype=torch.uint8, device=dev)
+        d_src[:n * chunks].copy_(torch.from_numpy(host[:n * chunks]))
+        d_out = torch.empty(3 * (n // 4 + 2) * chunks, dtype=torch.int32, device=dev)
+        d_off = torch.empty(chunks + 1, dtype=torch.int64, device=dev)
+        plan.run(d_src, off, d_out, d_off, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan.run(d_src, off, d_out, d_off, None)
+        torch.cuda.synchronize()
+        dt_find = time.perf_counter() - t0
+        stages = plan.last_timings()
+        plan.status()
+        pin = m4.PinnedBuffer(n * chunks + 4096)
+        plan.flate_encode(d_src, chunks, d_out, d_off, gzip=True, mtime=1, out=pin.array)  # warm: allocates the stream
+        nbytes, ms, kinds = plan.flate_encode(d_src, chunks, d_out, d_off, gzip=True, mtime=1, out=pin.array)
+        stream = bytes(pin.array[:nbytes])
+        pin.close()
+    except m4.M4GError as e:
+        return {"error": str(e)}
+    ok = gzip.decompress(stream) == host[:n * chunks].tobytes()
+    res = {
+        "level": 6, "m4_params": kw, "chunks": chunks,
+        "find_matches_value": round(chunks * n / dt_find / 1e9, 3), "find_matches_stage_ms": [round(x, 3) for x in stages],
+        "encode_value": round(chunks * n / (ms[2] * 1e-3) / 1e9, 3), "unit": "GB/s", "encode_ms_total": round(ms[2], 2),
+        "encode_ms_host_codes": round(ms[0], 2), "encode_ms_k6f_tokens": round(ms[1], 2),
+        "stream_bytes": nbytes, "compression_ratio": round(chunks * n / nbytes, 4),
+        "block_kinds": {k: int((kinds == i).sum()) for i, k in enumerate(("stored", "fixed", "dynamic"))},
+        "gzip_stream_inflates_to_input": ok,
+        "sample": f"the first {chunks} chunks of the workload as one gzip stream, one deflate block per chunk: "
+                  f"m4g_batch_run_device at flate level 6's M4 parameters, then m4g_batch_flate_encode (k5f symbol "
+                  f"counts, codes on host threads, k6f tokens, CRC-32 on the GPU, D2H into page-locked memory)",
+    }
+    if not no_cpu:
+        from oracle_lib import OracleFlateEncoder, OracleM4
+        k = min(chunks, 6)
+        lists = [OracleM4(**kw).FindMatches(host[c * n:(c + 1) * n]) for c in range(k)]
+        enc, ref = OracleFlateEncoder(True, 1), b""
+        t0 = time.perf_counter()
+        for c in range(k):
+            ref += enc.Encode(host[c * n:(c + 1) * n], lists[c], False)
+        dt = time.perf_counter() - t0
+        res["cpu_encode_s_per_GiB"] = round(dt / (k * n / 2**30), 3)
+        res["first_blocks_equal_restated_encoder"] = stream[:len(ref) - 8] == ref[:len(ref) - 8]
+    return res
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -150,6 +209,8 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-gpu-encode", action="store_true",
                     help="skip the m4g_batch_encode leg (Encoder pass 2 on the GPU, SURVEY 8f.2)")
+    ap.add_argument("--flate-chunks", type=int, default=256,
+                    help="chunks of the flate leg (M4 at flate level 6 + m4g_batch_flate_encode, SURVEY 8f.4); 0 = skip")
     ap.add_argument("--e2e-sample-chunks", type=int, default=512)
     ap.add_argument("--e2e-persistent-chunks", type=int, default=2048)
     return ap.parse_args()
@@ -490,6 +551,8 @@ def main():
         }
         pin_in.close()
         pin_out.close()
+    if rank == 0 and world == 1 and args.flate_chunks > 0 and args.kind == "text" and not args.no_gpu_encode:
+        out["gpu_flate"] = flate_leg(host, n, min(C, args.flate_chunks), dev, local_rank, args.no_cpu_baseline)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -1530,6 +1530,7 @@ __global__ __launch_bounds__(K5B_THREADS) void k5b_long_literals(
 
 } // namespace m4g
 #include "k6_encode.h"
+#include "k6_flate.h"
 namespace m4g {
 
 // ---------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 
 #include "kernels.h"
 #include "enc_host.h"
+#include "flate_host.h"
 
 #include <thread>
 
@@ -366,6 +367,7 @@ extern "C" const char *m4g_strerror(int code) {
   case M4G_ERR_NO_MEMORY: return "out of memory";
   case M4G_ERR_REPEAT_RANGE: return "seeded repeat distance reaches before the history start";
   case M4G_ERR_INTERNAL: return "internal error (kernel-side overflow); the output of the call is not valid";
+  case M4G_ERR_TOKEN_RANGE: return "a match is outside the flate token limits (Length 3..258, Distance 1..32768)";
   default: return code < 0 ? "output buffer too small (-(needed) returned)" : "ok";
   }
 }
@@ -427,6 +429,9 @@ struct m4g_batch {
   uint64_t *enc_pos = nullptr, *enc_bits = nullptr; // per chunk: body bit position / bits written
   uint32_t *enc_words = nullptr;   // the stream
   size_t enc_words_cap = 0;
+  uint32_t *enc_mode = nullptr;    // m4g_batch_flate_encode: per chunk, 0 = stored block
+  uint32_t *enc_crc = nullptr;     // m4g_batch_flate_encode (gzip): CRC-32 per 4 KiB segment
+  size_t enc_crc_cap = 0;
 };
 
 extern "C" void m4g_batch_destroy(m4g_batch *b) {
@@ -445,6 +450,8 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->enc_pos);
   (void)hipFree(b->enc_bits);
   (void)hipFree(b->enc_words);
+  (void)hipFree(b->enc_mode);
+  (void)hipFree(b->enc_crc);
   if (b->h_jobs) (void)hipHostFree(b->h_jobs);
   if (b->ev_jobs) (void)hipEventDestroy(b->ev_jobs);
   for (auto &e : b->ev)
@@ -718,7 +725,7 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
   const uint64_t end_pos = pos;
   if (flags & 2) pos += 2; // ISLAST + ISEMPTY (encoder.go:156-159)
   const uint64_t nbytes = (pos + 7) / 8;
-  if (nbytes > stream_cap) return -(int64_t)nbytes;
+  if (nbytes > stream_cap) return -(int64_t)(nbytes + M4G_STREAM_NEEDED_BIAS);
   if (!stream_out && nbytes) return fail(M4G_ERR_BAD_PARAM, "stream_out is NULL");
   const size_t nwords = (size_t)(nbytes / 4 + 2);
   if (nchunks > 0) {
@@ -769,6 +776,189 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
   if (ms_out) {
     ms_out[0] = std::chrono::duration<float, std::milli>(t_planned - t_begin).count();
     ms_out[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return (int64_t)nbytes;
+}
+
+// ===========================================================================
+// GPU flate / gzip encoder: huffmanBitWriter.Encode (flate/huffman_bit_writer.go:
+// 506-517) or gzipEncoder.Encode (flate/gzip.go:39-65) for every chunk of a batch
+// (include/m4g.h, m4g_batch_flate_encode).  k5f counts the symbols, the host
+// builds the codes and lays the stream out (flate_host.h), k6f writes the tokens.
+// ===========================================================================
+extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks, const m4g_match *d_out,
+                                          const uint64_t *d_out_off, int flags, uint32_t gzip_mtime,
+                                          uint8_t *stream_out, size_t stream_cap, void *hip_stream, float *ms_out,
+                                          uint8_t *kinds_out) {
+  using namespace m4g_flate;
+  if (!b || !d_out_off || (nchunks && (!d_src || !d_out))) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (b->last_off.size() != nchunks + 1)
+    return fail(M4G_ERR_BAD_PARAM, "m4g_batch_flate_encode: run the plan on these chunks first (m4g_batch_run_device)");
+  static_assert(kTab == KF_TAB && KF_TAB <= K6_TAB, "table strides");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const auto t_begin = std::chrono::steady_clock::now();
+  const bool gz = (flags & 4) != 0;
+  static const FixedCodes fx;
+  static const Crc32Join cj;
+  if (nchunks > 0) {
+    if (!b->enc_tables) {
+      if (hipMalloc(&b->enc_tables, b->max_chunks * (size_t)K6_TAB * 4) != hipSuccess ||
+          hipMalloc(&b->enc_pos, b->max_chunks * 8) != hipSuccess || hipMalloc(&b->enc_bits, b->max_chunks * 8) != hipSuccess)
+        return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the encoder tables failed");
+    }
+    if (!b->enc_mode && hipMalloc(&b->enc_mode, b->max_chunks * 4) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the encoder tables failed");
+  }
+  // pass 1 (makeStatistics) on the GPU; with gzip, the CRC-32 of every 4 KiB segment beside it
+  std::vector<uint32_t> stats(nchunks * (size_t)KF_TAB);
+  std::vector<uint32_t> seg_crc;
+  uint64_t max_len = 0;
+  for (size_t c = 0; c < nchunks; c++) max_len = std::max(max_len, b->last_off[c + 1] - b->last_off[c]);
+  const uint32_t segs = (uint32_t)((max_len + KC_SEG - 1) / KC_SEG);
+  if (nchunks > 0) {
+    hipLaunchKernelGGL(k5f_flate_stats, dim3((unsigned)nchunks), dim3(KF_THREADS), 0, st, d_src,
+                       reinterpret_cast<const uint32_t *>(d_out), b->W.d_jobs, d_out_off, b->enc_tables);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(stats.data(), b->enc_tables, stats.size() * 4, hipMemcpyDeviceToHost, st));
+    if (gz && segs > 0) {
+      const size_t nseg = nchunks * (size_t)segs;
+      if (nseg > b->enc_crc_cap) {
+        (void)hipFree(b->enc_crc);
+        b->enc_crc = nullptr;
+        b->enc_crc_cap = 0;
+        if (hipMalloc(&b->enc_crc, nseg * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the CRC buffer failed");
+        b->enc_crc_cap = nseg;
+      }
+      hipLaunchKernelGGL(k7_crc32_segments, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, d_src, b->W.d_jobs,
+                         (int)nchunks, segs, b->enc_crc);
+      HIP_TRY(hipGetLastError());
+      seg_crc.resize(nseg);
+      HIP_TRY(hipMemcpyAsync(seg_crc.data(), b->enc_crc, nseg * 4, hipMemcpyDeviceToHost, st));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  for (size_t c = 0; c < nchunks; c++)
+    if (stats[c * KF_TAB + KF_BAD])
+      return fail(M4G_ERR_TOKEN_RANGE, "m4g_batch_flate_encode: chunk " + std::to_string(c) + " holds " +
+                                           std::to_string(stats[c * KF_TAB + KF_BAD]) +
+                                           " match(es) outside Length 3..258 / Distance 1..32768; the reference's "
+                                           "lengthCode / offsetCode panic there (flate/token.go:59-71)");
+  // per chunk: codes, block kind, header bits, token bits -- on host threads
+  std::vector<ChunkPlan> plans(nchunks);
+  std::vector<uint32_t> tables(nchunks * (size_t)KF_TAB);
+  {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nt = (unsigned)std::min<size_t>(hw, (nchunks + 31) / 32 + 1);
+    auto work = [&](unsigned t) {
+      for (size_t c = t; c < nchunks; c += nt) {
+        plan_chunk(stats.data() + c * KF_TAB, (size_t)(b->last_off[c + 1] - b->last_off[c]), false,
+                   tables.data() + c * KF_TAB, plans[c], fx);
+        plans[c].header.flush();
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  const auto t_planned = std::chrono::steady_clock::now();
+  // bit positions: one bit writer for the whole stream (its pending bits carry over between Encode calls)
+  std::vector<uint64_t> hdr_pos(nchunks), body_pos(nchunks);
+  std::vector<uint32_t> mode(nchunks);
+  uint64_t pos = ((flags & 1) && gz) ? 80 : 0; // gzip header (gzip.go:40-53)
+  for (size_t c = 0; c < nchunks; c++) {
+    hdr_pos[c] = pos;
+    pos += plans[c].header.total;
+    mode[c] = plans[c].kind == kStored ? 0u : 1u;
+    if (plans[c].kind == kStored) pos = ((pos + 7) & ~7ull) + 32; // flush, LEN, NLEN (huffman_bit_writer.go:340-349)
+    body_pos[c] = pos;
+    pos += plans[c].token_bits + plans[c].eob.len;
+    if (kinds_out) kinds_out[c] = (uint8_t)plans[c].kind;
+  }
+  const uint64_t end_pos = pos;
+  if (flags & 2) {                    // Writer.Close() with nothing buffered: an empty last block, which comes out
+    pos = (pos + 3 + 7 + 7) & ~7ull;  // as a fixed block (3 header bits + the 7-bit end-of-block code), then flush()
+    if (gz) pos += 64;                // CRC-32 and length (gzip.go:60-63)
+  }
+  const uint64_t nbytes = (pos + 7) / 8;
+  if (nbytes > stream_cap) return -(int64_t)(nbytes + M4G_STREAM_NEEDED_BIAS);
+  if (!stream_out && nbytes) return fail(M4G_ERR_BAD_PARAM, "stream_out is NULL");
+  const size_t nwords = (size_t)(nbytes / 4 + 2);
+  if (nchunks > 0) {
+    if (nwords > b->enc_words_cap) {
+      (void)hipFree(b->enc_words);
+      b->enc_words = nullptr;
+      b->enc_words_cap = 0;
+      if (hipMalloc(&b->enc_words, nwords * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the stream failed");
+      b->enc_words_cap = nwords;
+    }
+    HIP_TRY(hipMemsetAsync(b->enc_words, 0, nwords * 4, st));
+    HIP_TRY(hipMemcpyAsync(b->enc_tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->enc_pos, body_pos.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->enc_mode, mode.data(), nchunks * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    hipLaunchKernelGGL(k6f_flate_bodies, dim3((unsigned)nchunks), dim3(KF_THREADS), 0, st, d_src,
+                       reinterpret_cast<const uint32_t *>(d_out), b->W.d_jobs, d_out_off, b->enc_tables, b->enc_pos,
+                       b->enc_mode, b->enc_words, b->enc_bits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    std::vector<uint64_t> written(nchunks);
+    HIP_TRY(hipMemcpyAsync(written.data(), b->enc_bits, nchunks * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(stream_out, b->enc_words, nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t c = 0; c < nchunks; c++)
+      if (written[c] != plans[c].token_bits)
+        return fail(M4G_ERR_INTERNAL, "m4g_batch_flate_encode: a chunk's token bits differ from the prediction of its "
+                                      "symbol counts (d_out / d_out_off are not from the plan's last run?)");
+    if (ms_out) HIP_TRY(hipEventElapsedTime(&ms_out[1], b->ev[0], b->ev[1]));
+  } else if (nbytes) {
+    std::memset(stream_out, 0, nbytes);
+  }
+  // the host-written fields share bytes with the tokens: OR them in
+  if ((flags & 1) && gz) {
+    const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, (uint8_t)gzip_mtime, (uint8_t)(gzip_mtime >> 8), (uint8_t)(gzip_mtime >> 16),
+                             (uint8_t)(gzip_mtime >> 24), 0, 255};
+    m4g_enc::or_bits(stream_out, 0, hdr, 80);
+  }
+  for (size_t c = 0; c < nchunks; c++) {
+    const ChunkPlan &P = plans[c];
+    m4g_enc::or_bits(stream_out, hdr_pos[c], P.header.dst.data(), P.header.total);
+    if (P.kind == kStored) {
+      const uint32_t len = (uint32_t)(b->last_off[c + 1] - b->last_off[c]);
+      const uint8_t f[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)~len, (uint8_t)(~len >> 8)};
+      m4g_enc::or_bits(stream_out, body_pos[c] - 32, f, 32);
+    } else {
+      const uint8_t e[2] = {(uint8_t)P.eob.code, (uint8_t)(P.eob.code >> 8)};
+      m4g_enc::or_bits(stream_out, body_pos[c] + P.token_bits, e, P.eob.len);
+    }
+  }
+  if (flags & 2) {
+    const uint8_t fin[2] = {3, 0}; // BFINAL = 1, BTYPE = 01; the fixed end-of-block code is 7 zero bits
+    m4g_enc::or_bits(stream_out, end_pos, fin, 10);
+    if (gz) {
+      uint32_t crc = 0;
+      uint64_t total = 0;
+      const uint32_t xp_seg = cj.x_pow_8n(KC_SEG);
+      for (size_t c = 0; c < nchunks; c++) {
+        const uint64_t len = b->last_off[c + 1] - b->last_off[c];
+        for (uint64_t s0 = 0, k = 0; s0 < len; s0 += KC_SEG, k++) {
+          const uint64_t sl = std::min<uint64_t>(KC_SEG, len - s0);
+          const uint32_t sc = seg_crc[c * (size_t)segs + k];
+          crc = sl == KC_SEG ? (Crc32Join::mul(xp_seg, crc) ^ sc) : cj.join(crc, sc, sl);
+        }
+        total += len;
+      }
+      const uint32_t len32 = (uint32_t)total; // gzip.go:57: a uint32 that wraps
+      const uint8_t tr[8] = {(uint8_t)crc,   (uint8_t)(crc >> 8),   (uint8_t)(crc >> 16),   (uint8_t)(crc >> 24),
+                             (uint8_t)len32, (uint8_t)(len32 >> 8), (uint8_t)(len32 >> 16), (uint8_t)(len32 >> 24)};
+      std::memcpy(stream_out + nbytes - 8, tr, 8);
+    }
+  }
+  if (ms_out) {
+    ms_out[0] = std::chrono::duration<float, std::milli>(t_planned - t_begin).count();
+    ms_out[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (nchunks == 0) ms_out[1] = 0.f;
   }
   return (int64_t)nbytes;
 }

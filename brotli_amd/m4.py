@@ -39,7 +39,7 @@ EXPORTS = [
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
     "m4g_batch_status", "m4g_batch_run_device_noalloc",
-    "m4g_batch_encode", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
+    "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
 ]
 
 _LIB = None
@@ -106,6 +106,9 @@ def lib():
         L.m4g_batch_encode.argtypes = [vp, vp, sz, vp, vp, vp, vp, ctypes.c_int, vp, sz, vp,
                                        ctypes.POINTER(ctypes.c_float)]
         L.m4g_batch_encode.restype = ctypes.c_int64
+        L.m4g_batch_flate_encode.argtypes = [vp, vp, sz, vp, vp, ctypes.c_int, ctypes.c_uint32, vp, sz, vp,
+                                             ctypes.POINTER(ctypes.c_float), vp]
+        L.m4g_batch_flate_encode.restype = ctypes.c_int64
         L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
@@ -115,8 +118,11 @@ def lib():
     return _LIB
 
 
+STREAM_NEEDED_BIAS = 2000000  # M4G_STREAM_NEEDED_BIAS
+
+
 def _check(rc: int, what: str):
-    if rc < ERR_BASE:
+    if -STREAM_NEEDED_BIAS < rc < ERR_BASE:
         L = lib()
         raise M4GError(f"{what}: {L.m4g_strerror(int(rc)).decode()} "
                        f"({L.m4g_last_error().decode()})")
@@ -394,8 +400,41 @@ class BatchPlan:
                                    buf.ctypes.data, cap, stream if stream else None, ms)
         _check(r, "m4g_batch_encode")
         if r < 0:
-            raise M4GError(f"m4g_batch_encode: stream_cap too small, need {-r}")
+            raise M4GError(f"m4g_batch_encode: stream_cap too small, need {-r - STREAM_NEEDED_BIAS}")
         return (int(r) if out is not None else buf[:r].tobytes()), [float(ms[k]) for k in range(3)]
+
+    def flate_encode(self, d_src, nchunks: int, d_out, d_out_off, first: bool = True, last: bool = True,
+                     gzip: bool = False, mtime: int = 0, stream: int = 0, cap: "int | None" = None,
+                     out: "np.ndarray | None" = None):
+        """m4g_batch_flate_encode: flate.NewEncoder() / NewGZIPEncoder() Encode for every
+        chunk of the plan's last run (flate/huffman_bit_writer.go, flate/gzip.go), symbol
+        counting and token writing on the GPU.  Returns (stream bytes or, with `out`, the
+        length; [host ms, kernel ms, total ms]; block kind per chunk: 0 stored, 1 fixed,
+        2 dynamic).  A match outside Length 3..258 / Distance 1..32768 raises M4GError
+        (the reference panics there, flate/token.go:59-71)."""
+        if out is not None:
+            buf, cap = out, out.size
+        else:
+            if cap is None:
+                cap = int(d_src.numel()) + (nchunks + 1) * 16 + 64
+            buf = np.zeros(cap, dtype=np.uint8)
+        ms = (ctypes.c_float * 3)()
+        kinds = np.zeros(max(nchunks, 1), dtype=np.uint8)
+        r = lib().m4g_batch_flate_encode(self._h, d_src.data_ptr(), nchunks, d_out.data_ptr(), d_out_off.data_ptr(),
+                                         (1 if first else 0) | (2 if last else 0) | (4 if gzip else 0), mtime,
+                                         buf.ctypes.data, cap, stream if stream else None, ms, kinds.ctypes.data)
+        _check(r, "m4g_batch_flate_encode")
+        if r < 0:
+            raise M4GError(f"m4g_batch_flate_encode: stream_cap too small, need {-r - STREAM_NEEDED_BIAS}")
+        return ((int(r) if out is not None else buf[:r].tobytes()), [float(ms[k]) for k in range(3)],
+                kinds[:nchunks].copy())
+
+
+def flate_m4_params(level: int) -> dict:
+    """The M4 fields flate.NewWriter / NewGZIPWriter use at levels 5..7 (flate/writer.go:33-46)."""
+    if not 5 <= level <= 7:
+        raise ValueError("flate levels 5..7 are the ones that use matchfinder.M4")
+    return dict(MaxDistance=1 << 15, ChainLength={5: 8, 6: 16, 7: 32}[level], HashLen=5, DistanceBitCost=66)
 
 
 def run_device_noalloc(d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0,

@@ -85,10 +85,16 @@ enum {
   M4G_ERR_NO_MEMORY = -1000005,
   M4G_ERR_REPEAT_RANGE = -1000006, /* seeded repeat distance reaches before the
                                       history start (the Go code would panic) */
+  M4G_ERR_TOKEN_RANGE = -1000008,  /* m4g_batch_flate_encode: a match outside
+                                    * Length 3..258 / Distance 1..32768 */
   M4G_ERR_INTERNAL = -1000007      /* a kernel-side capacity check failed; the
                                       output of that call is not valid */
 };
-/* Count-returning entry points use values >= -1000000 for "-(needed)". */
+/* Count-returning entry points use values >= -1000000 for "-(needed)"; the
+ * stream encoders (m4g_batch_encode, m4g_batch_flate_encode), whose outputs
+ * can be far larger, return -(needed + M4G_STREAM_NEEDED_BIAS) instead, which
+ * is below every M4G_ERR_* value. */
+#define M4G_STREAM_NEEDED_BIAS 2000000
 
 /* Human-readable text for an error code. */
 const char *m4g_strerror(int code);
@@ -246,7 +252,8 @@ void m4g_hostbatch_destroy(m4g_hostbatch *h);
  *                Without bit 1 the last byte may be partial (zero padded): a
  *                caller that continues the stream must carry those bits over.
  *   stream_out : host memory, stream_cap bytes.  Returns the stream length in
- *                bytes, -(needed) when stream_cap is too small, or an M4G_ERR_*.
+ *                bytes, -(needed + M4G_STREAM_NEEDED_BIAS) when stream_cap is too
+ *                small, or an M4G_ERR_*.
  *   ms_out     : nullable, 3 floats: host code building, K6 kernel, whole call (ms).
  * Synchronises hip_stream.  The bytes equal Encoder.Encode's up to the order in
  * which chooseBitDepths (brotli_bit_stream.go:571) sorts symbols of equal count
@@ -256,6 +263,44 @@ int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks,
                          const m4g_histo *d_histos, const m4g_code *d_codes,
                          int flags, uint8_t *stream_out, size_t stream_cap,
                          void *hip_stream, float *ms_out);
+
+/* Replaces: flate.NewEncoder().Encode(dst, chunk, matches, false) -- or
+ * flate.NewGZIPEncoder()'s, flags bit 2 -- called for every chunk of the batch
+ * in chunk order on ONE encoder (flate/huffman_bit_writer.go:506-517,
+ * flate/gzip.go:39-65), i.e. what matchfinder.Writer does after FindMatches when
+ * it was made by flate.NewWriter / NewGZIPWriter (flate/writer.go:14-66;
+ * levels 5-7 use matchfinder.M4 with MaxDistance 1<<15, HashLen 5,
+ * ChainLength 8 / 16 / 32, DistanceBitCost 66).  Input: the device-resident
+ * Match lists of the plan's last m4g_batch_run_device[_codes] call on these
+ * chunks.  makeStatistics (huffman_bit_writer.go:425-446) and writeTokens
+ * (472-504) run on the GPU; the code construction (huffman_code.go), the choice
+ * between a stored, a fixed and a dynamic block and the block headers
+ * (huffman_bit_writer.go:361-415) on host threads.  Every chunk becomes one
+ * deflate block; blocks follow each other at bit granularity as in the
+ * reference (the writer keeps its pending bits between Encode calls).
+ *   flags bit 0: this call starts a stream (gzip: the 10-byte header with
+ *                gzip_mtime where the reference writes time.Now(), gzip.go:46);
+ *         bit 1: it also ends it, as Writer.Close() with nothing buffered does
+ *                (matchfinder.go:89-93): an empty last block (which comes out as
+ *                a fixed block), flush to a byte and, for gzip, CRC-32 and
+ *                length of all chunks (computed on the GPU, joined on the host);
+ *         bit 2: gzip framing (flate/gzip.go) instead of raw deflate.
+ *                Without bit 1 the last byte may be partial (zero padded).
+ *   kinds_out  : nullable, one byte per chunk: 0 stored, 1 fixed, 2 dynamic.
+ *   ms_out     : nullable, 3 floats: host code building, token kernel, whole call.
+ * A match with Length outside 3..258 or Distance outside 1..32768 makes the
+ * reference panic (flate/token.go:59-71: nothing limits M4's match lengths);
+ * here the call fails with M4G_ERR_TOKEN_RANGE and names the chunk.
+ * Returns the stream length in bytes, -(needed + M4G_STREAM_NEEDED_BIAS) when
+ * stream_cap is too small, or an M4G_ERR_*.  Synchronises hip_stream.  The
+ * encoder has no sort without a total order, so the bytes are meant to equal
+ * the Go encoder's (unpinned here: no Go toolchain; pinned against the
+ * restated encoder and by inflating). */
+int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks,
+                               const m4g_match *d_out, const uint64_t *d_out_off,
+                               int flags, uint32_t gzip_mtime, uint8_t *stream_out,
+                               size_t stream_cap, void *hip_stream, float *ms_out,
+                               uint8_t *kinds_out);
 
 /* Kernel-side outcome of the plan's most recent m4g_batch_run_device[_codes]
  * call.  Those calls only enqueue work and return before it runs, so conditions
