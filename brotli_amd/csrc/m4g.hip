@@ -413,6 +413,27 @@ struct BatchWork {
   uint32_t *keys_own = nullptr;
 };
 
+// Device buffers of the flate encoder: owned by a plan (grown on demand) or by one call.
+struct FlateBuffers {
+  uint32_t *tables = nullptr;  // KF_TAB words per job: symbol counts, then code tables
+  uint64_t *pos = nullptr, *bits = nullptr;
+  uint32_t *mode = nullptr;
+  size_t jobs_cap = 0;
+  uint32_t *words = nullptr;
+  size_t words_cap = 0;
+  uint32_t *crc = nullptr;
+  size_t crc_cap = 0;
+  void release() {
+    (void)hipFree(tables);
+    (void)hipFree(pos);
+    (void)hipFree(bits);
+    (void)hipFree(mode);
+    (void)hipFree(words);
+    (void)hipFree(crc);
+    *this = FlateBuffers();
+  }
+};
+
 struct m4g_batch {
   int device = 0;
   Params p{};
@@ -429,9 +450,7 @@ struct m4g_batch {
   uint64_t *enc_pos = nullptr, *enc_bits = nullptr; // per chunk: body bit position / bits written
   uint32_t *enc_words = nullptr;   // the stream
   size_t enc_words_cap = 0;
-  uint32_t *enc_mode = nullptr;    // m4g_batch_flate_encode: per chunk, 0 = stored block
-  uint32_t *enc_crc = nullptr;     // m4g_batch_flate_encode (gzip): CRC-32 per 4 KiB segment
-  size_t enc_crc_cap = 0;
+  FlateBuffers flate;              // m4g_batch_flate_encode: its device buffers, grown on demand
 };
 
 extern "C" void m4g_batch_destroy(m4g_batch *b) {
@@ -450,8 +469,7 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->enc_pos);
   (void)hipFree(b->enc_bits);
   (void)hipFree(b->enc_words);
-  (void)hipFree(b->enc_mode);
-  (void)hipFree(b->enc_crc);
+  b->flate.release();
   if (b->h_jobs) (void)hipHostFree(b->h_jobs);
   if (b->ev_jobs) (void)hipEventDestroy(b->ev_jobs);
   for (auto &e : b->ev)
@@ -786,74 +804,79 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
 // (include/m4g.h, m4g_batch_flate_encode).  k5f counts the symbols, the host
 // builds the codes and lays the stream out (flate_host.h), k6f writes the tokens.
 // ===========================================================================
-extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks, const m4g_match *d_out,
-                                          const uint64_t *d_out_off, int flags, uint32_t gzip_mtime,
-                                          uint8_t *stream_out, size_t stream_cap, void *hip_stream, float *ms_out,
-                                          uint8_t *kinds_out) {
+namespace {
+// Jobs = deflate blocks in stream order (Job.src_off / start / len say where a block's bytes are; d_out_off[j]
+// .. d_out_off[j + 1] its matches).  last_is_final: the last job is the stream's last block (eof set, then
+// flush and, for gzip, the trailer); otherwise flags bit 1 appends the empty last block of Writer.Close().
+int64_t flate_encode_jobs(FlateBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const uint8_t *d_src, const Job *d_jobs,
+                          const std::vector<uint64_t> &lens, const m4g_match *d_out, const uint64_t *d_out_off, int flags,
+                          bool last_is_final, uint32_t gzip_mtime, uint8_t *stream_out, size_t stream_cap,
+                          hipStream_t st, float *ms_out, uint8_t *kinds_out, const char *what) {
   using namespace m4g_flate;
-  if (!b || !d_out_off || (nchunks && (!d_src || !d_out))) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
-  if (b->last_off.size() != nchunks + 1)
-    return fail(M4G_ERR_BAD_PARAM, "m4g_batch_flate_encode: run the plan on these chunks first (m4g_batch_run_device)");
-  static_assert(kTab == KF_TAB && KF_TAB <= K6_TAB, "table strides");
-  HIP_TRY(hipSetDevice(b->device));
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  static_assert(kTab == KF_TAB, "table strides");
+  const size_t njobs = lens.size();
   const auto t_begin = std::chrono::steady_clock::now();
   const bool gz = (flags & 4) != 0;
   static const FixedCodes fx;
   static const Crc32Join cj;
-  if (nchunks > 0) {
-    if (!b->enc_tables) {
-      if (hipMalloc(&b->enc_tables, b->max_chunks * (size_t)K6_TAB * 4) != hipSuccess ||
-          hipMalloc(&b->enc_pos, b->max_chunks * 8) != hipSuccess || hipMalloc(&b->enc_bits, b->max_chunks * 8) != hipSuccess)
-        return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the encoder tables failed");
-    }
-    if (!b->enc_mode && hipMalloc(&b->enc_mode, b->max_chunks * 4) != hipSuccess)
+  if (njobs > B.jobs_cap) {
+    (void)hipFree(B.tables);
+    (void)hipFree(B.pos);
+    (void)hipFree(B.bits);
+    (void)hipFree(B.mode);
+    B.tables = nullptr;
+    B.pos = B.bits = nullptr;
+    B.mode = nullptr;
+    B.jobs_cap = 0;
+    if (hipMalloc(&B.tables, njobs * (size_t)KF_TAB * 4) != hipSuccess || hipMalloc(&B.pos, njobs * 8) != hipSuccess ||
+        hipMalloc(&B.bits, njobs * 8) != hipSuccess || hipMalloc(&B.mode, njobs * 4) != hipSuccess)
       return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the encoder tables failed");
+    B.jobs_cap = njobs;
   }
   // pass 1 (makeStatistics) on the GPU; with gzip, the CRC-32 of every 4 KiB segment beside it
-  std::vector<uint32_t> stats(nchunks * (size_t)KF_TAB);
+  std::vector<uint32_t> stats(njobs * (size_t)KF_TAB);
   std::vector<uint32_t> seg_crc;
   uint64_t max_len = 0;
-  for (size_t c = 0; c < nchunks; c++) max_len = std::max(max_len, b->last_off[c + 1] - b->last_off[c]);
+  for (size_t c = 0; c < njobs; c++) max_len = std::max(max_len, lens[c]);
   const uint32_t segs = (uint32_t)((max_len + KC_SEG - 1) / KC_SEG);
-  if (nchunks > 0) {
-    hipLaunchKernelGGL(k5f_flate_stats, dim3((unsigned)nchunks), dim3(KF_THREADS), 0, st, d_src,
-                       reinterpret_cast<const uint32_t *>(d_out), b->W.d_jobs, d_out_off, b->enc_tables);
+  if (njobs > 0) {
+    hipLaunchKernelGGL(k5f_flate_stats, dim3((unsigned)njobs), dim3(KF_THREADS), 0, st, d_src,
+                       reinterpret_cast<const uint32_t *>(d_out), d_jobs, d_out_off, B.tables);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(stats.data(), b->enc_tables, stats.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(stats.data(), B.tables, stats.size() * 4, hipMemcpyDeviceToHost, st));
     if (gz && segs > 0) {
-      const size_t nseg = nchunks * (size_t)segs;
-      if (nseg > b->enc_crc_cap) {
-        (void)hipFree(b->enc_crc);
-        b->enc_crc = nullptr;
-        b->enc_crc_cap = 0;
-        if (hipMalloc(&b->enc_crc, nseg * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the CRC buffer failed");
-        b->enc_crc_cap = nseg;
+      const size_t nseg = njobs * (size_t)segs;
+      if (nseg > B.crc_cap) {
+        (void)hipFree(B.crc);
+        B.crc = nullptr;
+        B.crc_cap = 0;
+        if (hipMalloc(&B.crc, nseg * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the CRC buffer failed");
+        B.crc_cap = nseg;
       }
-      hipLaunchKernelGGL(k7_crc32_segments, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, d_src, b->W.d_jobs,
-                         (int)nchunks, segs, b->enc_crc);
+      hipLaunchKernelGGL(k7_crc32_segments, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, d_src, d_jobs,
+                         (int)njobs, segs, B.crc);
       HIP_TRY(hipGetLastError());
       seg_crc.resize(nseg);
-      HIP_TRY(hipMemcpyAsync(seg_crc.data(), b->enc_crc, nseg * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(seg_crc.data(), B.crc, nseg * 4, hipMemcpyDeviceToHost, st));
     }
   }
   HIP_TRY(hipStreamSynchronize(st));
-  for (size_t c = 0; c < nchunks; c++)
+  for (size_t c = 0; c < njobs; c++)
     if (stats[c * KF_TAB + KF_BAD])
-      return fail(M4G_ERR_TOKEN_RANGE, "m4g_batch_flate_encode: chunk " + std::to_string(c) + " holds " +
+      return fail(M4G_ERR_TOKEN_RANGE, std::string(what) + ": chunk " + std::to_string(c) + " holds " +
                                            std::to_string(stats[c * KF_TAB + KF_BAD]) +
                                            " match(es) outside Length 3..258 / Distance 1..32768; the reference's "
                                            "lengthCode / offsetCode panic there (flate/token.go:59-71)");
-  // per chunk: codes, block kind, header bits, token bits -- on host threads
-  std::vector<ChunkPlan> plans(nchunks);
-  std::vector<uint32_t> tables(nchunks * (size_t)KF_TAB);
+  // per block: codes, block kind, header bits, token bits -- on host threads
+  std::vector<ChunkPlan> plans(njobs);
+  std::vector<uint32_t> tables(njobs * (size_t)KF_TAB);
   {
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const unsigned nt = (unsigned)std::min<size_t>(hw, (nchunks + 31) / 32 + 1);
+    const unsigned nt = (unsigned)std::min<size_t>(hw, (njobs + 31) / 32 + 1);
     auto work = [&](unsigned t) {
-      for (size_t c = t; c < nchunks; c += nt) {
-        plan_chunk(stats.data() + c * KF_TAB, (size_t)(b->last_off[c + 1] - b->last_off[c]), false,
-                   tables.data() + c * KF_TAB, plans[c], fx);
+      for (size_t c = t; c < njobs; c += nt) {
+        plan_chunk(stats.data() + c * KF_TAB, (size_t)lens[c], last_is_final && c + 1 == njobs, tables.data() + c * KF_TAB,
+                   plans[c], fx);
         plans[c].header.flush();
       }
     };
@@ -864,10 +887,10 @@ extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, si
   }
   const auto t_planned = std::chrono::steady_clock::now();
   // bit positions: one bit writer for the whole stream (its pending bits carry over between Encode calls)
-  std::vector<uint64_t> hdr_pos(nchunks), body_pos(nchunks);
-  std::vector<uint32_t> mode(nchunks);
+  std::vector<uint64_t> hdr_pos(njobs), body_pos(njobs);
+  std::vector<uint32_t> mode(njobs);
   uint64_t pos = ((flags & 1) && gz) ? 80 : 0; // gzip header (gzip.go:40-53)
-  for (size_t c = 0; c < nchunks; c++) {
+  for (size_t c = 0; c < njobs; c++) {
     hdr_pos[c] = pos;
     pos += plans[c].header.total;
     mode[c] = plans[c].kind == kStored ? 0u : 1u;
@@ -877,41 +900,43 @@ extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, si
     if (kinds_out) kinds_out[c] = (uint8_t)plans[c].kind;
   }
   const uint64_t end_pos = pos;
-  if (flags & 2) {                    // Writer.Close() with nothing buffered: an empty last block, which comes out
-    pos = (pos + 3 + 7 + 7) & ~7ull;  // as a fixed block (3 header bits + the 7-bit end-of-block code), then flush()
+  const bool ends = last_is_final || (flags & 2);
+  if (ends) {
+    if (!last_is_final) pos += 3 + 7; // Writer.Close() with nothing buffered: an empty last block, which comes out
+                                      // as a fixed block (3 header bits + the 7-bit end-of-block code)
+    pos = (pos + 7) & ~7ull;          // flush() (huffman_bit_writer.go:510-512)
     if (gz) pos += 64;                // CRC-32 and length (gzip.go:60-63)
   }
   const uint64_t nbytes = (pos + 7) / 8;
   if (nbytes > stream_cap) return -(int64_t)(nbytes + M4G_STREAM_NEEDED_BIAS);
   if (!stream_out && nbytes) return fail(M4G_ERR_BAD_PARAM, "stream_out is NULL");
   const size_t nwords = (size_t)(nbytes / 4 + 2);
-  if (nchunks > 0) {
-    if (nwords > b->enc_words_cap) {
-      (void)hipFree(b->enc_words);
-      b->enc_words = nullptr;
-      b->enc_words_cap = 0;
-      if (hipMalloc(&b->enc_words, nwords * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the stream failed");
-      b->enc_words_cap = nwords;
+  if (njobs > 0) {
+    if (nwords > B.words_cap) {
+      (void)hipFree(B.words);
+      B.words = nullptr;
+      B.words_cap = 0;
+      if (hipMalloc(&B.words, nwords * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the stream failed");
+      B.words_cap = nwords;
     }
-    HIP_TRY(hipMemsetAsync(b->enc_words, 0, nwords * 4, st));
-    HIP_TRY(hipMemcpyAsync(b->enc_tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b->enc_pos, body_pos.data(), nchunks * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b->enc_mode, mode.data(), nchunks * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(b->ev[0], st));
-    hipLaunchKernelGGL(k6f_flate_bodies, dim3((unsigned)nchunks), dim3(KF_THREADS), 0, st, d_src,
-                       reinterpret_cast<const uint32_t *>(d_out), b->W.d_jobs, d_out_off, b->enc_tables, b->enc_pos,
-                       b->enc_mode, b->enc_words, b->enc_bits);
+    HIP_TRY(hipMemsetAsync(B.words, 0, nwords * 4, st));
+    HIP_TRY(hipMemcpyAsync(B.tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(B.pos, body_pos.data(), njobs * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(B.mode, mode.data(), njobs * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(k6f_flate_bodies, dim3((unsigned)njobs), dim3(KF_THREADS), 0, st, d_src,
+                       reinterpret_cast<const uint32_t *>(d_out), d_jobs, d_out_off, B.tables, B.pos, B.mode, B.words, B.bits);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->ev[1], st));
-    std::vector<uint64_t> written(nchunks);
-    HIP_TRY(hipMemcpyAsync(written.data(), b->enc_bits, nchunks * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(stream_out, b->enc_words, nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ev1, st));
+    std::vector<uint64_t> written(njobs);
+    HIP_TRY(hipMemcpyAsync(written.data(), B.bits, njobs * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(stream_out, B.words, nbytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    for (size_t c = 0; c < nchunks; c++)
+    for (size_t c = 0; c < njobs; c++)
       if (written[c] != plans[c].token_bits)
-        return fail(M4G_ERR_INTERNAL, "m4g_batch_flate_encode: a chunk's token bits differ from the prediction of its "
-                                      "symbol counts (d_out / d_out_off are not from the plan's last run?)");
-    if (ms_out) HIP_TRY(hipEventElapsedTime(&ms_out[1], b->ev[0], b->ev[1]));
+        return fail(M4G_ERR_INTERNAL, std::string(what) + ": a block's token bits differ from the prediction of its "
+                                                          "symbol counts (the match lists do not belong to these bytes?)");
+    if (ms_out) HIP_TRY(hipEventElapsedTime(&ms_out[1], ev0, ev1));
   } else if (nbytes) {
     std::memset(stream_out, 0, nbytes);
   }
@@ -921,11 +946,11 @@ extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, si
                              (uint8_t)(gzip_mtime >> 24), 0, 255};
     m4g_enc::or_bits(stream_out, 0, hdr, 80);
   }
-  for (size_t c = 0; c < nchunks; c++) {
+  for (size_t c = 0; c < njobs; c++) {
     const ChunkPlan &P = plans[c];
     m4g_enc::or_bits(stream_out, hdr_pos[c], P.header.dst.data(), P.header.total);
     if (P.kind == kStored) {
-      const uint32_t len = (uint32_t)(b->last_off[c + 1] - b->last_off[c]);
+      const uint32_t len = (uint32_t)lens[c];
       const uint8_t f[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)~len, (uint8_t)(~len >> 8)};
       m4g_enc::or_bits(stream_out, body_pos[c] - 32, f, 32);
     } else {
@@ -933,15 +958,17 @@ extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, si
       m4g_enc::or_bits(stream_out, body_pos[c] + P.token_bits, e, P.eob.len);
     }
   }
-  if (flags & 2) {
-    const uint8_t fin[2] = {3, 0}; // BFINAL = 1, BTYPE = 01; the fixed end-of-block code is 7 zero bits
-    m4g_enc::or_bits(stream_out, end_pos, fin, 10);
+  if (ends) {
+    if (!last_is_final) {
+      const uint8_t fin[2] = {3, 0}; // BFINAL = 1, BTYPE = 01; the fixed end-of-block code is 7 zero bits
+      m4g_enc::or_bits(stream_out, end_pos, fin, 10);
+    }
     if (gz) {
       uint32_t crc = 0;
       uint64_t total = 0;
       const uint32_t xp_seg = cj.x_pow_8n(KC_SEG);
-      for (size_t c = 0; c < nchunks; c++) {
-        const uint64_t len = b->last_off[c + 1] - b->last_off[c];
+      for (size_t c = 0; c < njobs; c++) {
+        const uint64_t len = lens[c];
         for (uint64_t s0 = 0, k = 0; s0 < len; s0 += KC_SEG, k++) {
           const uint64_t sl = std::min<uint64_t>(KC_SEG, len - s0);
           const uint32_t sc = seg_crc[c * (size_t)segs + k];
@@ -958,9 +985,85 @@ extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, si
   if (ms_out) {
     ms_out[0] = std::chrono::duration<float, std::milli>(t_planned - t_begin).count();
     ms_out[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    if (nchunks == 0) ms_out[1] = 0.f;
+    if (njobs == 0) ms_out[1] = 0.f;
   }
   return (int64_t)nbytes;
+}
+} // namespace
+
+extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks, const m4g_match *d_out,
+                                          const uint64_t *d_out_off, int flags, uint32_t gzip_mtime,
+                                          uint8_t *stream_out, size_t stream_cap, void *hip_stream, float *ms_out,
+                                          uint8_t *kinds_out) {
+  if (!b || !d_out_off || (nchunks && (!d_src || !d_out))) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (b->last_off.size() != nchunks + 1)
+    return fail(M4G_ERR_BAD_PARAM, "m4g_batch_flate_encode: run the plan on these chunks first (m4g_batch_run_device)");
+  HIP_TRY(hipSetDevice(b->device));
+  std::vector<uint64_t> lens(nchunks);
+  for (size_t c = 0; c < nchunks; c++) lens[c] = b->last_off[c + 1] - b->last_off[c];
+  return flate_encode_jobs(b->flate, b->ev[0], b->ev[1], d_src, b->W.d_jobs, lens, d_out, d_out_off, flags, false,
+                           gzip_mtime, stream_out, stream_cap, static_cast<hipStream_t>(hip_stream), ms_out, kinds_out,
+                           "m4g_batch_flate_encode");
+}
+
+// flate.NewWriter(dst, level) / NewGZIPWriter over one whole input, given the Match lists of its blocks
+// (m4g_find_matches_blocks): include/m4g.h.
+extern "C" int64_t m4g_flate_encode_blocks(int device, const uint8_t *src, size_t n, size_t block_size,
+                                           const m4g_match *matches, const uint64_t *block_off, int gzip,
+                                           uint32_t gzip_mtime, uint8_t *stream_out, size_t stream_cap,
+                                           uint8_t *kinds_out) {
+  if ((!src && n) || block_size == 0 || !block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
+  if (n >= ((uint64_t)1 << 32)) return fail(M4G_ERR_TOO_LARGE, "at most 4 GiB per call");
+  if (int rc = check_device(device)) return rc;
+  HIP_TRY(hipSetDevice(device));
+  // Writer.Write: every full block; Writer.Close: the remainder, possibly empty, as the last block
+  const size_t nfull = n / block_size, njobs = nfull + 1;
+  const size_t nlists = (n + block_size - 1) / block_size; // block_off has nlists + 1 entries
+  std::vector<Job> jobs(njobs);
+  std::vector<uint64_t> lens(njobs), off(njobs + 1);
+  for (size_t j = 0; j < njobs; j++) {
+    Job J{};
+    J.src_off = (uint64_t)j * block_size;
+    J.len = (uint32_t)std::min<uint64_t>(block_size, n - J.src_off);
+    jobs[j] = J;
+    lens[j] = J.len;
+    off[j] = block_off[std::min(j, nlists)];
+  }
+  off[njobs] = block_off[nlists];
+  const uint64_t nmatches = block_off[nlists];
+  if (nmatches && !matches) return fail(M4G_ERR_BAD_PARAM, "matches is NULL");
+  struct Scratch {
+    uint8_t *d_src = nullptr;
+    m4g_match *d_m = nullptr;
+    uint64_t *d_off = nullptr;
+    Job *d_jobs = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FlateBuffers B;
+    ~Scratch() {
+      (void)hipFree(d_src);
+      (void)hipFree(d_m);
+      (void)hipFree(d_off);
+      (void)hipFree(d_jobs);
+      B.release();
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (st) (void)hipStreamDestroy(st);
+    }
+  } S;
+  HIP_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&S.e0));
+  HIP_TRY(hipEventCreate(&S.e1));
+  if (hipMalloc(&S.d_src, n + 64) != hipSuccess || hipMalloc(&S.d_m, (nmatches + 1) * sizeof(m4g_match)) != hipSuccess ||
+      hipMalloc(&S.d_off, (njobs + 1) * 8) != hipSuccess || hipMalloc(&S.d_jobs, njobs * sizeof(Job)) != hipSuccess)
+    return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+  if (n) HIP_TRY(hipMemcpyAsync(S.d_src, src, n, hipMemcpyHostToDevice, S.st));
+  if (nmatches) HIP_TRY(hipMemcpyAsync(S.d_m, matches, nmatches * sizeof(m4g_match), hipMemcpyHostToDevice, S.st));
+  HIP_TRY(hipMemcpyAsync(S.d_off, off.data(), (njobs + 1) * 8, hipMemcpyHostToDevice, S.st));
+  HIP_TRY(hipMemcpyAsync(S.d_jobs, jobs.data(), njobs * sizeof(Job), hipMemcpyHostToDevice, S.st));
+  HIP_TRY(hipStreamSynchronize(S.st)); // (the host vectors above are pageable)
+  return flate_encode_jobs(S.B, S.e0, S.e1, S.d_src, S.d_jobs, lens, S.d_m, S.d_off, 1 | (gzip ? 4 : 0), true, gzip_mtime,
+                           stream_out, stream_cap, S.st, nullptr, kinds_out, "m4g_flate_encode_blocks");
 }
 
 // ===========================================================================

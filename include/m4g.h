@@ -302,6 +302,25 @@ int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunk
                                size_t stream_cap, void *hip_stream, float *ms_out,
                                uint8_t *kinds_out);
 
+/* Replaces: the encoder half of flate.NewWriter(dst, level) / NewGZIPWriter
+ * (flate/writer.go:14-66) over one whole input: Writer.Write(src) encodes every
+ * full block of block_size bytes as a non-final deflate block, Writer.Close()
+ * the remainder -- possibly empty -- as the final one (matchfinder.go:59-93).
+ * matches / block_off are what m4g_find_matches_blocks(ctx, src, n, block_size,
+ * ...) returned for the same bytes (block_off has ceil(n / block_size) + 1
+ * entries), i.e. the Match lists of the block-after-block FindMatches calls the
+ * Writer makes.  Host memory in, host memory out; the symbol counts, tokens and
+ * (gzip != 0) CRC-32 are computed on `device`.  With the level's M4 fields
+ * (see m4g_batch_flate_encode) the result is the stream the reference's writer
+ * produces for that level, gzip_mtime standing in for time.Now().  Returns the
+ * stream length, -(needed + M4G_STREAM_NEEDED_BIAS), M4G_ERR_TOKEN_RANGE where
+ * the reference panics, or another M4G_ERR_*.  kinds_out: nullable, one byte
+ * per block (n / block_size + 1 of them). */
+int64_t m4g_flate_encode_blocks(int device, const uint8_t *src, size_t n, size_t block_size,
+                                const m4g_match *matches, const uint64_t *block_off,
+                                int gzip, uint32_t gzip_mtime, uint8_t *stream_out,
+                                size_t stream_cap, uint8_t *kinds_out);
+
 /* Kernel-side outcome of the plan's most recent m4g_batch_run_device[_codes]
  * call.  Those calls only enqueue work and return before it runs, so conditions
  * the kernels detect cannot come back through their return value: this call

@@ -127,3 +127,29 @@ def test_flate_full_size_batch_inflates():
     assert pygzip.decompress(stream) == host.tobytes()
     want, _ = _encode_with_oracle(chunks[:3], LEVELS[6], gzip=True, mtime=7)
     assert stream[:len(want) - 16] == want[:len(want) - 16]
+
+
+@pytest.mark.parametrize("level,gz", [(5, False), (6, True), (7, False), (7, True)])
+def test_flate_writer_drop_in_on_the_reference_test_file(level, gz):
+    """flate_test.go:44-90 (TestWriterLevels / TestGZIPWriterLevels) for the M4 levels, end to end on the GPU:
+    match finding of all 64 KiB blocks with the history carried over (m4g_find_matches_blocks) + the encoder
+    (m4g_flate_encode_blocks).  The stream inflates to the file and equals, byte for byte, the restated
+    matchfinder.Writer{M4, flate encoder, BlockSize 1 << 16}."""
+    from oracle_lib import flate_compress as oracle_flate_compress
+    data = opticks()
+    out = m4.flate_compress(data, level, gzip=gz, mtime=12345)
+    assert (pygzip.decompress(out) if gz else _inflate(out)) == data
+    assert out == oracle_flate_compress(OracleM4(**LEVELS[level]), data, 1 << 16, gzip=gz, mtime=12345)
+
+
+def test_flate_writer_drop_in_edge_sizes():
+    from oracle_lib import flate_compress as oracle_flate_compress
+    rng = np.random.default_rng(9)
+    noise = bytes(rng.integers(0, 256, 70000, dtype=np.uint8))
+    text = synth.text(300000, 3)
+    for data, bs in ((b"", 1 << 16), (b"abc", 1 << 16), (text[:1 << 16], 1 << 16), (text[:(1 << 17)], 1 << 16),
+                     (text, 1 << 16), (noise + text[:50000] + noise, 1 << 16), (text[:100000], 4096),
+                     (noise[:4096 * 3], 4096)):
+        out = m4.flate_compress(data, 6, block_size=bs)
+        assert _inflate(out) == data
+        assert out == oracle_flate_compress(OracleM4(**LEVELS[6]), data, bs), (len(data), bs)
