@@ -194,3 +194,39 @@ func (q *M4) Batch(data []byte, chunkOff []uint64, devices []int, wantHistos boo
 	}
 	return
 }
+
+// FlateCompress is flate.NewWriter(&buf, level) -- gz: flate.NewGZIPWriter -- followed by w.Write(data);
+// w.Close(), for the levels whose match finder is matchfinder.M4 (5, 6, 7: flate/writer.go:33-46).  Match finding
+// for all 64 KiB blocks in one launch (history carried over, as the Writer's block-after-block FindMatches calls),
+// then the flate encoder on the GPU (m4g_flate_encode_blocks).  mtime stands in for the time.Now() of the gzip
+// header (flate/gzip.go:46).  Panics where the reference panics: a match longer than 258 bytes (flate/token.go:60).
+func FlateCompress(data []byte, level int, gz bool, mtime uint32, device int) []byte {
+	chain, ok := map[int]int{5: 8, 6: 16, 7: 32}[level]
+	if !ok {
+		panic("m4gpu: flate levels 5..7 use matchfinder.M4")
+	}
+	q := &M4{MaxDistance: 1 << 15, HashLen: 5, ChainLength: chain, DistanceBitCost: 66, Device: device}
+	const bs = 1 << 16 // flate/writer.go:65
+	q.init()
+	nb := (len(data) + bs - 1) / bs
+	ms := make([]C.m4g_match, len(data)/4+2*nb+2)
+	off := make([]C.uint64_t, nb+1)
+	var p *C.uint8_t
+	if len(data) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&data[0]))
+	}
+	if n := C.m4g_find_matches_blocks(q.ctx, p, C.size_t(len(data)), bs, &ms[0], C.size_t(len(ms)), &off[0]); n < 0 {
+		fail("m4g_find_matches_blocks", C.int(n))
+	}
+	out := make([]byte, len(data)+16*(nb+2)+64)
+	g := C.int(0)
+	if gz {
+		g = 1
+	}
+	n := C.m4g_flate_encode_blocks(C.int(device), p, C.size_t(len(data)), bs, &ms[0], &off[0], g, C.uint32_t(mtime),
+		(*C.uint8_t)(unsafe.Pointer(&out[0])), C.size_t(len(out)), nil)
+	if n < 0 {
+		fail("m4g_flate_encode_blocks", C.int(n))
+	}
+	return out[:n]
+}
