@@ -413,6 +413,22 @@ struct BatchWork {
   uint32_t *keys_own = nullptr;
 };
 
+// Device buffers of the brotli encoder (K6): owned by a plan (grown on demand) or by one call.
+struct EncBuffers {
+  uint32_t *tables = nullptr; // K6_TAB words per job
+  uint64_t *pos = nullptr, *bits = nullptr; // per job: body bit position / bits written
+  size_t jobs_cap = 0;
+  uint32_t *words = nullptr;  // the stream
+  size_t words_cap = 0;
+  void release() {
+    (void)hipFree(tables);
+    (void)hipFree(pos);
+    (void)hipFree(bits);
+    (void)hipFree(words);
+    *this = EncBuffers();
+  }
+};
+
 // Device buffers of the flate encoder: owned by a plan (grown on demand) or by one call.
 struct FlateBuffers {
   uint32_t *tables = nullptr;  // KF_TAB words per job: symbol counts, then code tables
@@ -445,11 +461,7 @@ struct m4g_batch {
   bool timing = false, ran = false;
   hipEvent_t ev[5] = {};
   hipStream_t last_stream = nullptr;
-  // m4g_batch_encode: device buffers, grown on demand
-  uint32_t *enc_tables = nullptr;  // K6_TAB words per chunk
-  uint64_t *enc_pos = nullptr, *enc_bits = nullptr; // per chunk: body bit position / bits written
-  uint32_t *enc_words = nullptr;   // the stream
-  size_t enc_words_cap = 0;
+  EncBuffers enc;                  // m4g_batch_encode: its device buffers, grown on demand
   FlateBuffers flate;              // m4g_batch_flate_encode: its device buffers, grown on demand
 };
 
@@ -465,10 +477,7 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->W.d_long_runs);
   (void)hipFree(b->W.split.hdr);
   (void)hipFree(b->W.keys_own);
-  (void)hipFree(b->enc_tables);
-  (void)hipFree(b->enc_pos);
-  (void)hipFree(b->enc_bits);
-  (void)hipFree(b->enc_words);
+  b->enc.release();
   b->flate.release();
   if (b->h_jobs) (void)hipHostFree(b->h_jobs);
   if (b->ev_jobs) (void)hipEventDestroy(b->ev_jobs);
@@ -695,16 +704,14 @@ extern "C" int m4g_batch_status(m4g_batch *b) {
 // m4g_batch_encode).  Pass 1 ran on the GPU already (K5: histograms + codes);
 // the prefix codes are built here on host threads (enc_host.h), pass 2 is K6.
 // ===========================================================================
-extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks, const m4g_match *d_out,
-                                    const uint64_t *d_out_off, const m4g_histo *d_histos, const m4g_code *d_codes,
-                                    int flags, uint8_t *stream_out, size_t stream_cap, void *hip_stream, float *ms_out) {
+namespace {
+// Jobs = meta-blocks in stream order; d_histos / d_codes from k5_histograms<true> over the same jobs.
+int64_t brotli_encode_jobs(EncBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const uint8_t *d_src, const Job *d_jobs,
+                           const std::vector<uint64_t> &lens, const m4g_match *d_out, const uint64_t *d_out_off,
+                           const m4g_histo *d_histos, const m4g_code *d_codes, int flags, uint8_t *stream_out,
+                           size_t stream_cap, hipStream_t st, float *ms_out, const char *what) {
   using namespace m4g_enc;
-  if (!b || !d_out_off || !d_histos || !d_codes || (nchunks && (!d_src || !d_out)))
-    return fail(M4G_ERR_BAD_PARAM, "NULL argument");
-  if (b->last_off.size() != nchunks + 1)
-    return fail(M4G_ERR_BAD_PARAM, "m4g_batch_encode: run the plan on these chunks first (m4g_batch_run_device_codes)");
-  HIP_TRY(hipSetDevice(b->device));
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const size_t nchunks = lens.size();
   const auto t_begin = std::chrono::steady_clock::now();
   // the histograms of the run (its kernels must have finished)
   std::vector<uint32_t> histos(nchunks * 1024);
@@ -720,9 +727,8 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
     const unsigned nt = (unsigned)std::min<size_t>(hw, (nchunks + 31) / 32 + 1);
     auto work = [&](unsigned t) {
       for (size_t c = t; c < nchunks; c += nt) {
-        const uint64_t len = b->last_off[c + 1] - b->last_off[c];
-        if (len == 0) continue; // Encode writes nothing for an empty block (encoder.go:24-31)
-        plan_chunk(histos.data() + c * 1024, (size_t)len, tables.data() + c * K6_TAB, plans[c], cl, cx);
+        if (lens[c] == 0) continue; // Encode writes nothing for an empty block (encoder.go:24-31)
+        plan_chunk(histos.data() + c * 1024, (size_t)lens[c], tables.data() + c * K6_TAB, plans[c], cl, cx);
         plans[c].prologue.flush();
       }
     };
@@ -747,36 +753,43 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
   if (!stream_out && nbytes) return fail(M4G_ERR_BAD_PARAM, "stream_out is NULL");
   const size_t nwords = (size_t)(nbytes / 4 + 2);
   if (nchunks > 0) {
-    if (!b->enc_tables) {
-      if (hipMalloc(&b->enc_tables, b->max_chunks * (size_t)K6_TAB * 4) != hipSuccess ||
-          hipMalloc(&b->enc_pos, b->max_chunks * 8) != hipSuccess || hipMalloc(&b->enc_bits, b->max_chunks * 8) != hipSuccess)
+    if (nchunks > B.jobs_cap) {
+      (void)hipFree(B.tables);
+      (void)hipFree(B.pos);
+      (void)hipFree(B.bits);
+      B.tables = nullptr;
+      B.pos = B.bits = nullptr;
+      B.jobs_cap = 0;
+      if (hipMalloc(&B.tables, nchunks * (size_t)K6_TAB * 4) != hipSuccess || hipMalloc(&B.pos, nchunks * 8) != hipSuccess ||
+          hipMalloc(&B.bits, nchunks * 8) != hipSuccess)
         return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the encoder tables failed");
+      B.jobs_cap = nchunks;
     }
-    if (nwords > b->enc_words_cap) {
-      (void)hipFree(b->enc_words);
-      b->enc_words = nullptr;
-      b->enc_words_cap = 0;
-      if (hipMalloc(&b->enc_words, nwords * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the stream failed");
-      b->enc_words_cap = nwords;
+    if (nwords > B.words_cap) {
+      (void)hipFree(B.words);
+      B.words = nullptr;
+      B.words_cap = 0;
+      if (hipMalloc(&B.words, nwords * 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the stream failed");
+      B.words_cap = nwords;
     }
-    HIP_TRY(hipMemsetAsync(b->enc_words, 0, nwords * 4, st));
-    HIP_TRY(hipMemcpyAsync(b->enc_tables, tables.data(), nchunks * (size_t)K6_TAB * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b->enc_pos, body_pos.data(), nchunks * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(b->ev[0], st));
+    HIP_TRY(hipMemsetAsync(B.words, 0, nwords * 4, st));
+    HIP_TRY(hipMemcpyAsync(B.tables, tables.data(), nchunks * (size_t)K6_TAB * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(B.pos, body_pos.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(k6_emit_bodies, dim3((unsigned)nchunks), dim3(K6_THREADS), 0, st, d_src,
-                       reinterpret_cast<const uint32_t *>(d_out), reinterpret_cast<const CodeRec *>(d_codes), b->W.d_jobs,
-                       d_out_off, b->enc_tables, b->enc_pos, b->enc_words, b->enc_bits);
+                       reinterpret_cast<const uint32_t *>(d_out), reinterpret_cast<const CodeRec *>(d_codes), d_jobs,
+                       d_out_off, B.tables, B.pos, B.words, B.bits);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->ev[1], st));
+    HIP_TRY(hipEventRecord(ev1, st));
     std::vector<uint64_t> written(nchunks);
-    HIP_TRY(hipMemcpyAsync(written.data(), b->enc_bits, nchunks * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(stream_out, b->enc_words, nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(written.data(), B.bits, nchunks * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(stream_out, B.words, nbytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t c = 0; c < nchunks; c++)
       if (written[c] != plans[c].body_bits)
-        return fail(M4G_ERR_INTERNAL, "m4g_batch_encode: a chunk's body length differs from the histogram prediction "
-                                      "(d_out / d_histos / d_codes are not from the same run?)");
-    if (ms_out) HIP_TRY(hipEventElapsedTime(&ms_out[1], b->ev[0], b->ev[1]));
+        return fail(M4G_ERR_INTERNAL, std::string(what) + ": a chunk's body length differs from the histogram prediction "
+                                                          "(d_out / d_histos / d_codes are not from the same run?)");
+    if (ms_out) HIP_TRY(hipEventElapsedTime(&ms_out[1], ev0, ev1));
   } else if (nbytes) {
     std::memset(stream_out, 0, nbytes);
   }
@@ -794,8 +807,140 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
   if (ms_out) {
     ms_out[0] = std::chrono::duration<float, std::milli>(t_planned - t_begin).count();
     ms_out[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (nchunks == 0) ms_out[1] = 0.f;
   }
   return (int64_t)nbytes;
+}
+
+// Device copies of one stream's bytes, Match lists and block jobs (the *_encode_blocks entry points):
+// Writer.Write encodes every full block, Writer.Close the remainder -- possibly empty -- as the last one.
+struct BlockUpload {
+  uint8_t *d_src = nullptr;
+  m4g_match *d_m = nullptr;
+  uint64_t *d_off = nullptr;
+  Job *d_jobs = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<Job> jobs;
+  std::vector<uint64_t> lens, off;
+  uint64_t nmatches = 0;
+  ~BlockUpload() {
+    (void)hipFree(d_src);
+    (void)hipFree(d_m);
+    (void)hipFree(d_off);
+    (void)hipFree(d_jobs);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  int init(int device, const uint8_t *src, size_t n, size_t block_size, const m4g_match *matches, const uint64_t *block_off) {
+    if ((!src && n) || block_size == 0 || !block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
+    if (n >= ((uint64_t)1 << 32)) return fail(M4G_ERR_TOO_LARGE, "at most 4 GiB per call");
+    if (block_size >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "block_size must stay below 2^31");
+    if (int rc = check_device(device)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    const size_t nfull = n / block_size, njobs = nfull + 1;
+    const size_t nlists = (n + block_size - 1) / block_size; // block_off has nlists + 1 entries
+    jobs.resize(njobs);
+    lens.resize(njobs);
+    off.resize(njobs + 1);
+    for (size_t j = 0; j < njobs; j++) {
+      Job J{};
+      J.src_off = (uint64_t)j * block_size;
+      J.len = (uint32_t)std::min<uint64_t>(block_size, n - J.src_off);
+      jobs[j] = J;
+      lens[j] = J.len;
+      off[j] = block_off[std::min(j, nlists)];
+    }
+    off[njobs] = block_off[nlists];
+    nmatches = block_off[nlists];
+    if (nmatches && !matches) return fail(M4G_ERR_BAD_PARAM, "matches is NULL");
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    if (hipMalloc(&d_src, n + 64) != hipSuccess || hipMalloc(&d_m, (nmatches + 1) * sizeof(m4g_match)) != hipSuccess ||
+        hipMalloc(&d_off, (njobs + 1) * 8) != hipSuccess || hipMalloc(&d_jobs, njobs * sizeof(Job)) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+    if (n) HIP_TRY(hipMemcpyAsync(d_src, src, n, hipMemcpyHostToDevice, st));
+    if (nmatches) HIP_TRY(hipMemcpyAsync(d_m, matches, nmatches * sizeof(m4g_match), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_off, off.data(), (njobs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), njobs * sizeof(Job), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st)); // (the host buffers above may be pageable)
+    return M4G_OK;
+  }
+};
+} // namespace
+
+extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunks, const m4g_match *d_out,
+                                    const uint64_t *d_out_off, const m4g_histo *d_histos, const m4g_code *d_codes,
+                                    int flags, uint8_t *stream_out, size_t stream_cap, void *hip_stream, float *ms_out) {
+  if (!b || !d_out_off || !d_histos || !d_codes || (nchunks && (!d_src || !d_out)))
+    return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (b->last_off.size() != nchunks + 1)
+    return fail(M4G_ERR_BAD_PARAM, "m4g_batch_encode: run the plan on these chunks first (m4g_batch_run_device_codes)");
+  HIP_TRY(hipSetDevice(b->device));
+  std::vector<uint64_t> lens(nchunks);
+  for (size_t c = 0; c < nchunks; c++) lens[c] = b->last_off[c + 1] - b->last_off[c];
+  return brotli_encode_jobs(b->enc, b->ev[0], b->ev[1], d_src, b->W.d_jobs, lens, d_out, d_out_off, d_histos, d_codes,
+                            flags, stream_out, stream_cap, static_cast<hipStream_t>(hip_stream), ms_out, "m4g_batch_encode");
+}
+
+// matchfinder.Writer{MatchFinder: M4, Encoder: &brotli.Encoder{}, BlockSize} over one whole input, given the Match
+// lists of its blocks (m4g_find_matches_blocks): include/m4g.h.
+extern "C" int64_t m4g_brotli_encode_blocks(int device, const uint8_t *src, size_t n, size_t block_size,
+                                            const m4g_match *matches, const uint64_t *block_off, uint8_t *stream_out,
+                                            size_t stream_cap) {
+  BlockUpload U;
+  if (int rc = U.init(device, src, n, block_size, matches, block_off)) return rc;
+  const size_t njobs = U.jobs.size();
+  // pass 1 of Encoder.Encode for every block (K5); literal runs of K5_HUGE bytes or more go to the side kernel,
+  // whose list K4 builds in the batch pipeline and the host builds here
+  std::vector<LongRun> runs;
+  uint32_t max_len = 0;
+  for (size_t j = 0; j < njobs; j++) {
+    uint32_t pos = 0;
+    max_len = std::max(max_len, U.jobs[j].len);
+    for (uint64_t k = U.off[j]; k < U.off[j + 1]; k++) {
+      if (matches[k].length == 1) // no copy length code for 1 (command.go:128); M4 never returns it with MinLength >= 2
+        return fail(M4G_ERR_BAD_PARAM, "m4g_brotli_encode_blocks: a match of Length 1");
+      if (matches[k].unmatched >= K5_HUGE) runs.push_back(LongRun{(uint32_t)j, pos, matches[k].unmatched, 0});
+      pos += matches[k].unmatched + matches[k].length;
+    }
+  }
+  struct Dev {
+    uint32_t *histos = nullptr;
+    CodeRec *codes = nullptr;
+    LongRun *runs = nullptr;
+    uint32_t *nruns = nullptr;
+    EncBuffers B;
+    ~Dev() {
+      (void)hipFree(histos);
+      (void)hipFree(codes);
+      (void)hipFree(runs);
+      (void)hipFree(nruns);
+      B.release();
+    }
+  } D;
+  const uint32_t nruns = (uint32_t)runs.size();
+  if (hipMalloc(&D.histos, njobs * sizeof(m4g_histo)) != hipSuccess ||
+      hipMalloc(&D.codes, (U.nmatches + 1) * sizeof(CodeRec)) != hipSuccess ||
+      hipMalloc(&D.runs, (runs.size() + 1) * sizeof(LongRun)) != hipSuccess || hipMalloc(&D.nruns, 4) != hipSuccess)
+    return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+  if (nruns) HIP_TRY(hipMemcpyAsync(D.runs, runs.data(), runs.size() * sizeof(LongRun), hipMemcpyHostToDevice, U.st));
+  HIP_TRY(hipMemcpyAsync(D.nruns, &nruns, 4, hipMemcpyHostToDevice, U.st));
+  hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, U.st, U.d_src,
+                     reinterpret_cast<const uint32_t *>(U.d_m), U.d_jobs, U.d_off, (uint64_t)U.nmatches, D.histos, D.codes);
+  HIP_TRY(hipGetLastError());
+  const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
+  if (nruns) {
+    hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, U.st, U.d_src, U.d_jobs, D.runs, D.nruns,
+                       nruns, segs, U.d_off, (uint64_t)U.nmatches, D.histos);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(U.st)); // (`nruns` and `runs` are stack / pageable)
+  return brotli_encode_jobs(D.B, U.e0, U.e1, U.d_src, U.d_jobs, U.lens, U.d_m, U.d_off,
+                            reinterpret_cast<const m4g_histo *>(D.histos), reinterpret_cast<const m4g_code *>(D.codes), 3,
+                            stream_out, stream_cap, U.st, nullptr, "m4g_brotli_encode_blocks");
 }
 
 // ===========================================================================
@@ -1012,58 +1157,14 @@ extern "C" int64_t m4g_flate_encode_blocks(int device, const uint8_t *src, size_
                                            const m4g_match *matches, const uint64_t *block_off, int gzip,
                                            uint32_t gzip_mtime, uint8_t *stream_out, size_t stream_cap,
                                            uint8_t *kinds_out) {
-  if ((!src && n) || block_size == 0 || !block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
-  if (n >= ((uint64_t)1 << 32)) return fail(M4G_ERR_TOO_LARGE, "at most 4 GiB per call");
-  if (int rc = check_device(device)) return rc;
-  HIP_TRY(hipSetDevice(device));
-  // Writer.Write: every full block; Writer.Close: the remainder, possibly empty, as the last block
-  const size_t nfull = n / block_size, njobs = nfull + 1;
-  const size_t nlists = (n + block_size - 1) / block_size; // block_off has nlists + 1 entries
-  std::vector<Job> jobs(njobs);
-  std::vector<uint64_t> lens(njobs), off(njobs + 1);
-  for (size_t j = 0; j < njobs; j++) {
-    Job J{};
-    J.src_off = (uint64_t)j * block_size;
-    J.len = (uint32_t)std::min<uint64_t>(block_size, n - J.src_off);
-    jobs[j] = J;
-    lens[j] = J.len;
-    off[j] = block_off[std::min(j, nlists)];
-  }
-  off[njobs] = block_off[nlists];
-  const uint64_t nmatches = block_off[nlists];
-  if (nmatches && !matches) return fail(M4G_ERR_BAD_PARAM, "matches is NULL");
-  struct Scratch {
-    uint8_t *d_src = nullptr;
-    m4g_match *d_m = nullptr;
-    uint64_t *d_off = nullptr;
-    Job *d_jobs = nullptr;
-    hipStream_t st = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+  BlockUpload U;
+  if (int rc = U.init(device, src, n, block_size, matches, block_off)) return rc;
+  struct Dev {
     FlateBuffers B;
-    ~Scratch() {
-      (void)hipFree(d_src);
-      (void)hipFree(d_m);
-      (void)hipFree(d_off);
-      (void)hipFree(d_jobs);
-      B.release();
-      if (e0) (void)hipEventDestroy(e0);
-      if (e1) (void)hipEventDestroy(e1);
-      if (st) (void)hipStreamDestroy(st);
-    }
-  } S;
-  HIP_TRY(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&S.e0));
-  HIP_TRY(hipEventCreate(&S.e1));
-  if (hipMalloc(&S.d_src, n + 64) != hipSuccess || hipMalloc(&S.d_m, (nmatches + 1) * sizeof(m4g_match)) != hipSuccess ||
-      hipMalloc(&S.d_off, (njobs + 1) * 8) != hipSuccess || hipMalloc(&S.d_jobs, njobs * sizeof(Job)) != hipSuccess)
-    return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
-  if (n) HIP_TRY(hipMemcpyAsync(S.d_src, src, n, hipMemcpyHostToDevice, S.st));
-  if (nmatches) HIP_TRY(hipMemcpyAsync(S.d_m, matches, nmatches * sizeof(m4g_match), hipMemcpyHostToDevice, S.st));
-  HIP_TRY(hipMemcpyAsync(S.d_off, off.data(), (njobs + 1) * 8, hipMemcpyHostToDevice, S.st));
-  HIP_TRY(hipMemcpyAsync(S.d_jobs, jobs.data(), njobs * sizeof(Job), hipMemcpyHostToDevice, S.st));
-  HIP_TRY(hipStreamSynchronize(S.st)); // (the host vectors above are pageable)
-  return flate_encode_jobs(S.B, S.e0, S.e1, S.d_src, S.d_jobs, lens, S.d_m, S.d_off, 1 | (gzip ? 4 : 0), true, gzip_mtime,
-                           stream_out, stream_cap, S.st, nullptr, kinds_out, "m4g_flate_encode_blocks");
+    ~Dev() { B.release(); }
+  } D;
+  return flate_encode_jobs(D.B, U.e0, U.e1, U.d_src, U.d_jobs, U.lens, U.d_m, U.d_off, 1 | (gzip ? 4 : 0), true, gzip_mtime,
+                           stream_out, stream_cap, U.st, nullptr, kinds_out, "m4g_flate_encode_blocks");
 }
 
 // ===========================================================================

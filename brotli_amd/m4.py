@@ -39,7 +39,7 @@ EXPORTS = [
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
     "m4g_batch_status", "m4g_batch_run_device_noalloc",
-    "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
+    "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
 ]
 
 _LIB = None
@@ -111,6 +111,8 @@ def lib():
         L.m4g_batch_flate_encode.restype = ctypes.c_int64
         L.m4g_flate_encode_blocks.argtypes = [ctypes.c_int, vp, sz, sz, vp, vp, ctypes.c_int, ctypes.c_uint32, vp, sz, vp]
         L.m4g_flate_encode_blocks.restype = ctypes.c_int64
+        L.m4g_brotli_encode_blocks.argtypes = [ctypes.c_int, vp, sz, sz, vp, vp, vp, sz]
+        L.m4g_brotli_encode_blocks.restype = ctypes.c_int64
         L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
@@ -430,6 +432,25 @@ class BatchPlan:
             raise M4GError(f"m4g_batch_flate_encode: stream_cap too small, need {-r - STREAM_NEEDED_BIAS}")
         return ((int(r) if out is not None else buf[:r].tobytes()), [float(ms[k]) for k in range(3)],
                 kinds[:nchunks].copy())
+
+
+def brotli_compress(data, block_size: int = 1 << 16, device: int = 0, **m4_fields) -> bytes:
+    """matchfinder.Writer{MatchFinder: &matchfinder.M4{**m4_fields}, Encoder: &brotli.Encoder{}, BlockSize}:
+    w.Write(data); w.Close() -- the writer of the reference's tests (brotli_test.go:626-649, 730-744) -- with
+    match finding (m4g_find_matches_blocks) and both passes of Encoder.Encode (m4g_brotli_encode_blocks) on the
+    GPU.  Returns the brotli stream."""
+    a = _as_u8(data)
+    mf = M4(device=device, **m4_fields)
+    matches, off = mf.find_matches_blocks(a, block_size)
+    cap = a.size + (a.size // block_size + 2) * 1024 + 64
+    buf = np.zeros(cap, dtype=np.uint8)
+    m = np.ascontiguousarray(matches, dtype=np.uint32)
+    r = lib().m4g_brotli_encode_blocks(device, a.ctypes.data if a.size else None, a.size, block_size,
+                                       m.ctypes.data if m.size else None, off.ctypes.data, buf.ctypes.data, cap)
+    _check(r, "m4g_brotli_encode_blocks")
+    if r < 0:
+        raise M4GError(f"m4g_brotli_encode_blocks: stream_cap too small, need {-r - STREAM_NEEDED_BIAS}")
+    return buf[:r].tobytes()
 
 
 def flate_compress(data, level: int = 6, gzip: bool = False, mtime: int = 0, block_size: int = 1 << 16,

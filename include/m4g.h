@@ -302,6 +302,21 @@ int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, size_t nchunk
                                size_t stream_cap, void *hip_stream, float *ms_out,
                                uint8_t *kinds_out);
 
+/* Replaces: the encoder half of matchfinder.Writer{MatchFinder: &M4{...},
+ * Encoder: &brotli.Encoder{}, BlockSize: block_size} over one whole input
+ * (the writer the reference's own tests build, brotli_test.go:626-649,
+ * 730-744): Write(src) encodes every full block as one meta-block, Close() the
+ * remainder -- possibly empty -- followed by ISLAST + ISEMPTY
+ * (matchfinder.go:59-93, encoder.go:17-161).  matches / block_off are what
+ * m4g_find_matches_blocks(ctx, src, n, block_size, ...) returned for the same
+ * bytes.  Host memory in, host memory out; both passes of Encoder.Encode run
+ * on `device` (K5 with the per-match codes, then K6), the prefix codes on host
+ * threads.  Returns the stream length, -(needed + M4G_STREAM_NEEDED_BIAS), or
+ * an M4G_ERR_*.  Byte identity with Go: as m4g_batch_encode. */
+int64_t m4g_brotli_encode_blocks(int device, const uint8_t *src, size_t n, size_t block_size,
+                                 const m4g_match *matches, const uint64_t *block_off,
+                                 uint8_t *stream_out, size_t stream_cap);
+
 /* Replaces: the encoder half of flate.NewWriter(dst, level) / NewGZIPWriter
  * (flate/writer.go:14-66) over one whole input: Writer.Write(src) encodes every
  * full block of block_size bytes as a non-final deflate block, Writer.Close()

@@ -230,3 +230,27 @@ func FlateCompress(data []byte, level int, gz bool, mtime uint32, device int) []
 	}
 	return out[:n]
 }
+
+// BrotliCompress is matchfinder.Writer{MatchFinder: q's parameters, Encoder: &brotli.Encoder{}, BlockSize: blockSize}
+// followed by w.Write(data); w.Close() (the writer of brotli_test.go:626-649): match finding for all blocks in one
+// launch, both passes of Encoder.Encode on the GPU (m4g_brotli_encode_blocks).
+func (q *M4) BrotliCompress(data []byte, blockSize int) []byte {
+	q.init()
+	nb := (len(data) + blockSize - 1) / blockSize
+	ms := make([]C.m4g_match, len(data)/q.minLength()+2*nb+2)
+	off := make([]C.uint64_t, nb+1)
+	var p *C.uint8_t
+	if len(data) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&data[0]))
+	}
+	if n := C.m4g_find_matches_blocks(q.ctx, p, C.size_t(len(data)), C.size_t(blockSize), &ms[0], C.size_t(len(ms)), &off[0]); n < 0 {
+		fail("m4g_find_matches_blocks", C.int(n))
+	}
+	out := make([]byte, len(data)+1024*(nb+2)+64)
+	n := C.m4g_brotli_encode_blocks(C.int(q.Device), p, C.size_t(len(data)), C.size_t(blockSize), &ms[0], &off[0],
+		(*C.uint8_t)(unsafe.Pointer(&out[0])), C.size_t(len(out)))
+	if n < 0 {
+		fail("m4g_brotli_encode_blocks", C.int(n))
+	}
+	return out[:n]
+}

@@ -86,3 +86,29 @@ def test_encode_full_size_batch_decodes():
     ref = _encode_with_oracle(chunks[:2], PARAMS_G)
     # same bytes up to the last full byte of chunk 1's meta-block (the oracle's stream ends there with ISLAST)
     assert stream[:len(ref) - 2] == ref[:len(ref) - 2]
+
+
+@pytest.mark.parametrize("kw", __import__("cases").PARAMS_REF_TESTS[:3] + [PARAMS_G],
+                         ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()) or "defaults")
+def test_writer_drop_in_on_the_reference_test_file(kw):
+    """SURVEY config 1 end to end on the GPU: matchfinder.Writer{M4{...}, brotli.Encoder, BlockSize 1 << 16} over
+    Isaac.Newton-Opticks.txt (brotli_test.go:626-649, 730-744): match finding of all blocks with the history carried
+    over (m4g_find_matches_blocks) + both passes of Encoder.Encode (m4g_brotli_encode_blocks).  The stream decodes to
+    the file and equals, byte for byte, the restated Writer's."""
+    data = opticks()
+    out = m4.brotli_compress(data, 1 << 16, **kw)
+    assert brotli_decompress(out, len(data)) == data
+    want, _ = OracleM4(**kw).compress(data, 1 << 16)
+    assert out == want
+
+
+def test_writer_drop_in_edge_sizes():
+    rng = np.random.default_rng(11)
+    noise = bytes(rng.integers(0, 256, 70000, dtype=np.uint8))
+    text = synth.text(300000, 5)
+    for data, bs in ((b"", 1 << 16), (b"abc", 1 << 16), (text[:1 << 16], 1 << 16), (text[:1 << 17], 1 << 16),
+                     (text, 1 << 16), (noise + text[:50000] + noise, 1 << 16), (text[:100000], 4096),
+                     (noise[:4096 * 3], 4096), (bytes(200000), 1 << 16)):
+        out = m4.brotli_compress(data, bs, **PARAMS_G)
+        assert brotli_decompress(out, len(data)) == data
+        assert out == OracleM4(**PARAMS_G).compress(data, bs)[0], (len(data), bs)
