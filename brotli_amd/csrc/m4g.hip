@@ -2260,8 +2260,27 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
   // The one-launch path needs: more than one block, at most one block end and
   // one slide per K1 tile, and a bounded slide list.  Otherwise: block by block.
   const uint64_t W = (uint64_t)p.max_distance;
-  const bool fast = nblocks >= 2 && block_size >= (size_t)kK1MaxTile + 7 && W >= (uint64_t)kK1MaxTile &&
-                    n / W + 2 < (size_t)kStreamMaxSlides && nblocks < ((size_t)1 << 24);
+  const bool shape_ok = nblocks >= 2 && block_size >= (size_t)kK1MaxTile + 7 && W >= (uint64_t)kK1MaxTile;
+  if (shape_ok && (n / W + 2 >= (size_t)kStreamMaxSlides || nblocks >= ((size_t)1 << 24))) {
+    // more history slides than one launch's list holds (a small MaxDistance: flate's 32 KiB window slides at
+    // every block): spans of whole blocks, each one launch; the handle carries the state from span to span
+    const size_t span_blocks = std::max<size_t>(2, std::min<size_t>(((size_t)kStreamMaxSlides - 3) * W / block_size,
+                                                                   ((size_t)1 << 24) - 1));
+    int64_t total = 0;
+    for (size_t b0 = 0; b0 < nblocks; b0 += span_blocks) {
+      const size_t nb = std::min(span_blocks, nblocks - b0);
+      const size_t len = std::min(n - b0 * block_size, nb * block_size);
+      std::vector<uint64_t> off(nb + 1);
+      const int64_t r = m4g_find_matches_blocks(c, src + b0 * block_size, len, block_size, out + total,
+                                                out_cap - (size_t)total, off.data());
+      if (r < 0) return r;
+      if (block_off)
+        for (size_t k = 1; k <= nb; k++) block_off[b0 + k] = (uint64_t)total + off[k];
+      total += r;
+    }
+    return total;
+  }
+  const bool fast = shape_ok;
   if (!fast) {
     int64_t total = 0;
     for (size_t b = 0; b < nblocks; b++) {

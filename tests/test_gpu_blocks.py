@@ -59,6 +59,23 @@ def test_blocks_equal_sequential_calls(case, kind):
         assert same(got2[int(off2[b]):int(off2[b + 1])], r), f"second call, block {b}"
 
 
+def test_blocks_more_slides_than_one_launch_holds():
+    """A small MaxDistance slides the history at (almost) every block -- flate's 32 KiB window does; the slide list
+    of one launch holds 4096 entries, so a long stream is cut into spans of whole blocks inside the call.  Here:
+    MaxDistance 4096, 18 MiB in 8 KiB blocks = 4608 slides."""
+    kw = dict(MaxDistance=4096, HashLen=5, ChainLength=4, DistanceBitCost=66)
+    n = 18 << 20
+    data = synth.text(n + 30000, 123)
+    g, o = m4.M4(**kw), OracleM4(**kw)
+    got, off = g.find_matches_blocks(data[:n], 8192)
+    ref = oracle_blocks(o, data[:n], 8192)
+    assert len(off) == len(ref) + 1
+    for b, r in enumerate(ref):
+        assert same(got[int(off[b]):int(off[b + 1])], r), f"block {b} of {len(ref)}"
+    assert g.history_len() == o.history_len()
+    assert same(g.find_matches(data[n:]), o.FindMatches(data[n:]))
+
+
 def test_blocks_degenerate_inputs():
     kw = dict(MaxDistance=1 << 16, DistanceBitCost=66)
     for data in (bytes(300000), b"ab" * 150000, (b"0123456789" * 50 + b"xyz") * 700):
