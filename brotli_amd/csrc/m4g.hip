@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -429,6 +430,11 @@ struct EncBuffers {
   }
 };
 
+struct GzipCarry {
+  uint32_t crc = 0;   // CRC-32 of the bytes encoded so far
+  uint64_t total = 0; // their number
+};
+
 // Device buffers of the flate encoder: owned by a plan (grown on demand) or by one call.
 struct FlateBuffers {
   uint32_t *tables = nullptr;  // KF_TAB words per job: symbol counts, then code tables
@@ -709,7 +715,10 @@ namespace {
 int64_t brotli_encode_jobs(EncBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const uint8_t *d_src, const Job *d_jobs,
                            const std::vector<uint64_t> &lens, const m4g_match *d_out, const uint64_t *d_out_off,
                            const m4g_histo *d_histos, const m4g_code *d_codes, int flags, uint8_t *stream_out,
-                           size_t stream_cap, hipStream_t st, float *ms_out, const char *what) {
+                           size_t stream_cap, hipStream_t st, float *ms_out, const char *what,
+                           unsigned start_bits = 0, uint64_t *end_bits_out = nullptr) {
+  // start_bits (< 8): the stream continues one whose last byte holds that many bits; they belong to the caller,
+  // who ORs them into byte 0 of stream_out.  end_bits_out: the bit position where this call stopped.
   using namespace m4g_enc;
   const size_t nchunks = lens.size();
   const auto t_begin = std::chrono::steady_clock::now();
@@ -740,7 +749,7 @@ int64_t brotli_encode_jobs(EncBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const 
   const auto t_planned = std::chrono::steady_clock::now();
   // bit positions (one bit writer for the whole stream: bitwriter.go state carries over between blocks)
   std::vector<uint64_t> body_pos(nchunks + 1), pro_pos(nchunks);
-  uint64_t pos = (flags & 1) ? 4 : 0; // stream header: WBITS = 24 (encoder.go:19-22)
+  uint64_t pos = start_bits + ((flags & 1) ? 4 : 0); // stream header: WBITS = 24 (encoder.go:19-22)
   for (size_t c = 0; c < nchunks; c++) {
     pro_pos[c] = pos;
     body_pos[c] = pos + plans[c].prologue.total;
@@ -748,6 +757,7 @@ int64_t brotli_encode_jobs(EncBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const 
   }
   const uint64_t end_pos = pos;
   if (flags & 2) pos += 2; // ISLAST + ISEMPTY (encoder.go:156-159)
+  if (end_bits_out) *end_bits_out = pos;
   const uint64_t nbytes = (pos + 7) / 8;
   if (nbytes > stream_cap) return -(int64_t)(nbytes + M4G_STREAM_NEEDED_BIAS);
   if (!stream_out && nbytes) return fail(M4G_ERR_BAD_PARAM, "stream_out is NULL");
@@ -796,7 +806,7 @@ int64_t brotli_encode_jobs(EncBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const 
   // the host-written fields share bytes with the bodies: OR them in
   if (flags & 1) {
     const uint8_t hdr = 15;
-    or_bits(stream_out, 0, &hdr, 4);
+    or_bits(stream_out, start_bits, &hdr, 4);
   }
   for (size_t c = 0; c < nchunks; c++)
     if (plans[c].prologue.total) or_bits(stream_out, pro_pos[c], plans[c].prologue.dst.data(), plans[c].prologue.total);
@@ -833,14 +843,18 @@ struct BlockUpload {
     if (e1) (void)hipEventDestroy(e1);
     if (st) (void)hipStreamDestroy(st);
   }
-  int init(int device, const uint8_t *src, size_t n, size_t block_size, const m4g_match *matches, const uint64_t *block_off) {
+  // whole_stream: jobs = every full block + the remainder, possibly empty (Write; Close).  Otherwise exactly the
+  // ceil(n / block_size) blocks of the lists.
+  int init(int device, const uint8_t *src, size_t n, size_t block_size, const m4g_match *matches, const uint64_t *block_off,
+           bool whole_stream = true) {
     if ((!src && n) || block_size == 0 || !block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
     if (n >= ((uint64_t)1 << 32)) return fail(M4G_ERR_TOO_LARGE, "at most 4 GiB per call");
     if (block_size >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "block_size must stay below 2^31");
     if (int rc = check_device(device)) return rc;
     HIP_TRY(hipSetDevice(device));
-    const size_t nfull = n / block_size, njobs = nfull + 1;
     const size_t nlists = (n + block_size - 1) / block_size; // block_off has nlists + 1 entries
+    const size_t nfull = n / block_size, njobs = whole_stream ? nfull + 1 : nlists;
+    if (njobs == 0) return fail(M4G_ERR_BAD_PARAM, "no block");
     jobs.resize(njobs);
     lens.resize(njobs);
     off.resize(njobs + 1);
@@ -956,7 +970,10 @@ namespace {
 int64_t flate_encode_jobs(FlateBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const uint8_t *d_src, const Job *d_jobs,
                           const std::vector<uint64_t> &lens, const m4g_match *d_out, const uint64_t *d_out_off, int flags,
                           bool last_is_final, uint32_t gzip_mtime, uint8_t *stream_out, size_t stream_cap,
-                          hipStream_t st, float *ms_out, uint8_t *kinds_out, const char *what) {
+                          hipStream_t st, float *ms_out, uint8_t *kinds_out, const char *what,
+                          unsigned start_bits = 0, uint64_t *end_bits_out = nullptr, GzipCarry *carry = nullptr) {
+  // start_bits / end_bits_out: as brotli_encode_jobs.  carry: CRC-32 and length of the stream's earlier bytes;
+  // this call's bytes are joined onto it (gzip only).
   using namespace m4g_flate;
   static_assert(kTab == KF_TAB, "table strides");
   const size_t njobs = lens.size();
@@ -1034,7 +1051,7 @@ int64_t flate_encode_jobs(FlateBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const
   // bit positions: one bit writer for the whole stream (its pending bits carry over between Encode calls)
   std::vector<uint64_t> hdr_pos(njobs), body_pos(njobs);
   std::vector<uint32_t> mode(njobs);
-  uint64_t pos = ((flags & 1) && gz) ? 80 : 0; // gzip header (gzip.go:40-53)
+  uint64_t pos = start_bits + (((flags & 1) && gz) ? 80 : 0); // gzip header (gzip.go:40-53)
   for (size_t c = 0; c < njobs; c++) {
     hdr_pos[c] = pos;
     pos += plans[c].header.total;
@@ -1052,6 +1069,7 @@ int64_t flate_encode_jobs(FlateBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const
     pos = (pos + 7) & ~7ull;          // flush() (huffman_bit_writer.go:510-512)
     if (gz) pos += 64;                // CRC-32 and length (gzip.go:60-63)
   }
+  if (end_bits_out) *end_bits_out = pos;
   const uint64_t nbytes = (pos + 7) / 8;
   if (nbytes > stream_cap) return -(int64_t)(nbytes + M4G_STREAM_NEEDED_BIAS);
   if (!stream_out && nbytes) return fail(M4G_ERR_BAD_PARAM, "stream_out is NULL");
@@ -1089,7 +1107,7 @@ int64_t flate_encode_jobs(FlateBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const
   if ((flags & 1) && gz) {
     const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, (uint8_t)gzip_mtime, (uint8_t)(gzip_mtime >> 8), (uint8_t)(gzip_mtime >> 16),
                              (uint8_t)(gzip_mtime >> 24), 0, 255};
-    m4g_enc::or_bits(stream_out, 0, hdr, 80);
+    m4g_enc::or_bits(stream_out, start_bits, hdr, 80);
   }
   for (size_t c = 0; c < njobs; c++) {
     const ChunkPlan &P = plans[c];
@@ -1103,25 +1121,28 @@ int64_t flate_encode_jobs(FlateBuffers &B, hipEvent_t ev0, hipEvent_t ev1, const
       m4g_enc::or_bits(stream_out, body_pos[c] + P.token_bits, e, P.eob.len);
     }
   }
+  GzipCarry run = carry ? *carry : GzipCarry{};
+  if (gz) { // CRC-32 of the stream so far (gzip.go:57-58)
+    const uint32_t xp_seg = cj.x_pow_8n(KC_SEG);
+    for (size_t c = 0; c < njobs; c++) {
+      const uint64_t len = lens[c];
+      for (uint64_t s0 = 0, k = 0; s0 < len; s0 += KC_SEG, k++) {
+        const uint64_t sl = std::min<uint64_t>(KC_SEG, len - s0);
+        const uint32_t sc = seg_crc[c * (size_t)segs + k];
+        run.crc = sl == KC_SEG ? (Crc32Join::mul(xp_seg, run.crc) ^ sc) : cj.join(run.crc, sc, sl);
+      }
+      run.total += len;
+    }
+    if (carry) *carry = run;
+  }
   if (ends) {
     if (!last_is_final) {
       const uint8_t fin[2] = {3, 0}; // BFINAL = 1, BTYPE = 01; the fixed end-of-block code is 7 zero bits
       m4g_enc::or_bits(stream_out, end_pos, fin, 10);
     }
     if (gz) {
-      uint32_t crc = 0;
-      uint64_t total = 0;
-      const uint32_t xp_seg = cj.x_pow_8n(KC_SEG);
-      for (size_t c = 0; c < njobs; c++) {
-        const uint64_t len = lens[c];
-        for (uint64_t s0 = 0, k = 0; s0 < len; s0 += KC_SEG, k++) {
-          const uint64_t sl = std::min<uint64_t>(KC_SEG, len - s0);
-          const uint32_t sc = seg_crc[c * (size_t)segs + k];
-          crc = sl == KC_SEG ? (Crc32Join::mul(xp_seg, crc) ^ sc) : cj.join(crc, sc, sl);
-        }
-        total += len;
-      }
-      const uint32_t len32 = (uint32_t)total; // gzip.go:57: a uint32 that wraps
+      const uint32_t crc = run.crc;
+      const uint32_t len32 = (uint32_t)run.total; // gzip.go:57: a uint32 that wraps
       const uint8_t tr[8] = {(uint8_t)crc,   (uint8_t)(crc >> 8),   (uint8_t)(crc >> 16),   (uint8_t)(crc >> 24),
                              (uint8_t)len32, (uint8_t)(len32 >> 8), (uint8_t)(len32 >> 16), (uint8_t)(len32 >> 24)};
       std::memcpy(stream_out + nbytes - 8, tr, 8);
@@ -2239,8 +2260,33 @@ extern "C" int64_t m4g_find_matches(m4g_ctx *c, const uint8_t *src, size_t n,
 // array the blocks are independent jobs; K1 builds the chain in segments, each
 // primed with the MaxDistance bytes before it (kernels.h, StreamInfo).
 // ---------------------------------------------------------------------------
+namespace {
+// What m4g_writer hangs into a block-parallel launch: its encoder runs on the device-resident results (bytes,
+// block jobs, Match lists, offsets) before the handle's history is compacted, so neither the Match lists nor
+// the bytes cross PCIe a second time.  Only the one-launch path calls it (blocks_one_launch_ok).
+struct BlocksHook {
+  LongRun *d_long_runs = nullptr; // K4 fills these for k5b when set (brotli)
+  uint32_t *d_n_long = nullptr;
+  uint32_t long_cap = 0;
+  std::function<int(const uint8_t *d_src, const Job *d_blocks, const std::vector<uint64_t> &lens, const m4g_match *d_out,
+                    const uint64_t *d_off, uint64_t nmatches, hipStream_t st)> fn;
+};
+bool blocks_one_launch_ok(const Params &p, size_t n, size_t block_size) {
+  const size_t nblocks = (n + block_size - 1) / block_size;
+  return nblocks >= 2 && block_size >= (size_t)kK1MaxTile + 7 && (uint64_t)p.max_distance >= (uint64_t)kK1MaxTile;
+}
+int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_size, m4g_match *out, size_t out_cap,
+                         uint64_t *block_off, BlocksHook *hook);
+} // namespace
+
 extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_size,
                                            m4g_match *out, size_t out_cap, uint64_t *block_off) {
+  return find_blocks_impl(c, src, n, block_size, out, out_cap, block_off, nullptr);
+}
+
+namespace {
+int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_size, m4g_match *out, size_t out_cap,
+                         uint64_t *block_off, BlocksHook *hook) {
   if (!c || (!src && n) || (!out && out_cap) || block_size == 0)
     return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
   const Params &p = c->p;
@@ -2250,12 +2296,13 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
   size_t need = 0;
   for (size_t b = 0; b < nblocks; b++)
     need += std::min(block_size, n - b * block_size) / (size_t)p.min_length + 2;
-  if (out_cap < need && n != 0) {
+  if (out_cap < need && n != 0 && !hook) {
     g_last_error = "out_cap below the sum of len/min_length + 2 over the blocks";
     return -(int64_t)need;
   }
   if (block_off) block_off[0] = 0;
   if (n == 0) return 0;
+  if (hook && !blocks_one_launch_ok(p, n, block_size)) return fail(M4G_ERR_INTERNAL, "hook outside the one-launch path");
 
   // The one-launch path needs: more than one block, at most one block end and
   // one slide per K1 tile, and a bounded slide list.  Otherwise: block by block.
@@ -2271,8 +2318,8 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
       const size_t nb = std::min(span_blocks, nblocks - b0);
       const size_t len = std::min(n - b0 * block_size, nb * block_size);
       std::vector<uint64_t> off(nb + 1);
-      const int64_t r = m4g_find_matches_blocks(c, src + b0 * block_size, len, block_size, out + total,
-                                                out_cap - (size_t)total, off.data());
+      const int64_t r = find_blocks_impl(c, src + b0 * block_size, len, block_size, hook ? nullptr : out + total,
+                                         hook ? 0 : out_cap - (size_t)total, off.data(), hook);
       if (r < 0) return r;
       if (block_off)
         for (size_t k = 1; k <= nb; k++) block_off[b0 + k] = (uint64_t)total + off[k];
@@ -2409,7 +2456,9 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
   if ((rc = launch_parse(p, c->d_hist, x_end, c->d_chain, d_blocks, (int)nblocks, c->wb, c->d_bcounts,
                          c->d_counts + 1, c->st)))
     return rc;
-  if ((rc = launch_compact(c->wb, d_blocks, c->d_bcounts, (int)nblocks, c->d_boff, c->d_out, c->out_cap, c->st)))
+  if (hook && hook->d_n_long) HIP_TRY(hipMemsetAsync(hook->d_n_long, 0, 4, c->st));
+  if ((rc = launch_compact(c->wb, d_blocks, c->d_bcounts, (int)nblocks, c->d_boff, c->d_out, c->out_cap, c->st,
+                           hook ? hook->d_long_runs : nullptr, hook ? hook->d_n_long : nullptr, hook ? hook->long_cap : 0u)))
     return rc;
 
   std::vector<uint64_t> off(nblocks + 1);
@@ -2417,6 +2466,14 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
   HIP_TRY(hipMemcpyAsync(off.data(), c->d_boff, (nblocks + 1) * 8, hipMemcpyDeviceToHost, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
   tr.mark("blocks: kernels");
+  if (hook) { // the encoder, on the device-resident results, before the history moves
+    if (int rce = status_from_error_word(c->h_counts[1])) return rce;
+    if (off[nblocks] > c->out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
+    std::vector<uint64_t> lens(nblocks);
+    for (size_t b = 0; b < nblocks; b++) lens[b] = std::min<uint64_t>(block_size, n - b * block_size);
+    if ((rc = hook->fn(c->d_hist, d_blocks, lens, c->d_out, c->d_boff, off[nblocks], c->st))) return rc;
+    tr.mark("blocks: encoder hook");
+  }
 
   // the handle continues as after the last block's call: history = buffer from the final origin on
   const uint64_t new_len = x_end - org;
@@ -2443,8 +2500,8 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
 
   if (int rce = status_from_error_word(c->h_counts[1])) return rce;
   const uint64_t cnt = off[nblocks];
-  if (cnt > c->out_cap || cnt > out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
-  if (cnt) {
+  if (cnt > c->out_cap || (!hook && cnt > out_cap)) return fail(M4G_ERR_HIP, "internal: match count above bound");
+  if (cnt && !hook) {
     HIP_TRY(hipMemcpyAsync(c->h_recs, c->d_out, (size_t)cnt * sizeof(m4g_match), hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     std::memcpy(out, c->h_recs, (size_t)cnt * sizeof(m4g_match));
@@ -2456,6 +2513,7 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
     for (size_t b = 0; b <= nblocks; b++) block_off[b] = off[b];
   return (int64_t)cnt;
 }
+} // namespace
 
 extern "C" int m4g_debug_dump_tables(m4g_ctx *c, uint32_t *table, uint32_t *chain, size_t chain_cap) {
   if (!c) return fail(M4G_ERR_BAD_PARAM, "ctx is NULL");
@@ -2468,4 +2526,262 @@ extern "C" int m4g_debug_dump_tables(m4g_ctx *c, uint32_t *table, uint32_t *chai
     HIP_TRY(hipMemcpy(chain, c->d_chain, k * 4, hipMemcpyDeviceToHost));
   }
   return M4G_OK;
+}
+
+// ===========================================================================
+// m4g_writer: matchfinder.Writer (matchfinder/matchfinder.go:44-103) with the
+// match finder AND the encoder on the GPU (include/m4g.h).
+// ===========================================================================
+struct m4g_writer {
+  m4g_ctx *ctx = nullptr;
+  int device = 0, format = 0;
+  size_t bs = 0;
+  uint32_t mtime = 0;
+  std::vector<uint8_t> inbuf; // Writer.inBuf: bytes that do not make up a block yet
+  std::vector<uint8_t> outq;  // produced, not yet handed to the caller
+  bool wrote_header = false;
+  uint8_t pend_byte = 0;      // the bit writer's pending bits (bitwriter.go:11-17, huffman_bit_writer.go:68-70)
+  unsigned pend_bits = 0;
+  GzipCarry carry;
+  EncBuffers eb;
+  FlateBuffers fb;
+  uint32_t *d_histos = nullptr;
+  size_t histos_cap = 0;
+  CodeRec *d_codes = nullptr;
+  size_t codes_cap = 0;
+  LongRun *d_runs = nullptr;
+  uint32_t *d_nruns = nullptr;
+  size_t runs_cap = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  std::vector<uint8_t> stage;
+  bool closed_pending = false; // Close() has encoded the last block; its bytes wait for a large enough `out`
+};
+
+namespace {
+int writer_reserve_brotli(m4g_writer *w, size_t njobs, uint64_t nmatches, size_t nruns) {
+  if (njobs > w->histos_cap) {
+    (void)hipFree(w->d_histos);
+    w->d_histos = nullptr;
+    w->histos_cap = 0;
+    if (hipMalloc(&w->d_histos, njobs * sizeof(m4g_histo)) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+    w->histos_cap = njobs;
+  }
+  if (nmatches + 1 > w->codes_cap) {
+    (void)hipFree(w->d_codes);
+    w->d_codes = nullptr;
+    w->codes_cap = 0;
+    if (hipMalloc(&w->d_codes, (nmatches + 1) * sizeof(CodeRec)) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+    w->codes_cap = nmatches + 1;
+  }
+  if (nruns + 1 > w->runs_cap) {
+    (void)hipFree(w->d_runs);
+    w->d_runs = nullptr;
+    w->runs_cap = 0;
+    if (hipMalloc(&w->d_runs, (nruns + 1) * sizeof(LongRun)) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+    w->runs_cap = nruns + 1;
+  }
+  if (!w->d_nruns && hipMalloc(&w->d_nruns, 4) != hipSuccess) return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+  return M4G_OK;
+}
+
+// The encoder over device-resident blocks: what Writer.writeBlock does after FindMatches, for all of them.
+// brotli: d_runs / d_nruns already hold the literal runs of K5_HUGE bytes or more.
+int writer_encode(m4g_writer *w, const uint8_t *d_src, const Job *d_jobs, const std::vector<uint64_t> &lens,
+                  const m4g_match *d_out, const uint64_t *d_off, uint64_t nmatches, hipStream_t st, bool final) {
+  uint64_t total = 0, max_len = 0;
+  for (uint64_t l : lens) total += l, max_len = std::max(max_len, l);
+  w->stage.resize((size_t)(total + total / 4) + lens.size() * 1024 + 128); // (fixed codes: up to 9 bits per literal)
+  uint64_t end_bits = 0;
+  int64_t r;
+  const int first = w->wrote_header ? 0 : 1;
+  if (w->format == M4G_FORMAT_BROTLI) {
+    const size_t njobs = lens.size();
+    hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
+                       reinterpret_cast<const uint32_t *>(d_out), d_jobs, d_off, (uint64_t)nmatches, w->d_histos, w->d_codes);
+    HIP_TRY(hipGetLastError());
+    const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
+    hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, st, d_src, d_jobs, w->d_runs, w->d_nruns,
+                       (uint32_t)(w->runs_cap - 1), segs, d_off, (uint64_t)nmatches, w->d_histos);
+    HIP_TRY(hipGetLastError());
+    r = brotli_encode_jobs(w->eb, w->e0, w->e1, d_src, d_jobs, lens, d_out, d_off,
+                           reinterpret_cast<const m4g_histo *>(w->d_histos), reinterpret_cast<const m4g_code *>(w->d_codes),
+                           first | (final ? 2 : 0), w->stage.data(), w->stage.size(), st, nullptr, "m4g_writer",
+                           w->pend_bits, &end_bits);
+  } else {
+    r = flate_encode_jobs(w->fb, w->e0, w->e1, d_src, d_jobs, lens, d_out, d_off,
+                          first | (w->format == M4G_FORMAT_GZIP ? 4 : 0), final, w->mtime, w->stage.data(), w->stage.size(),
+                          st, nullptr, nullptr, "m4g_writer", w->pend_bits, &end_bits, &w->carry);
+  }
+  if (r < 0) return r < -M4G_STREAM_NEEDED_BIAS ? fail(M4G_ERR_INTERNAL, "m4g_writer: staging buffer too small") : (int)r;
+  if (r > 0) w->stage[0] |= w->pend_byte;
+  w->wrote_header = true;
+  const uint64_t whole = final ? (uint64_t)r : end_bits / 8;
+  w->outq.insert(w->outq.end(), w->stage.begin(), w->stage.begin() + (size_t)whole);
+  w->pend_bits = final ? 0u : (unsigned)(end_bits & 7);
+  w->pend_byte = w->pend_bits ? w->stage[(size_t)whole] : 0;
+  return M4G_OK;
+}
+
+// blocks of `bs` bytes of span (the last one may be shorter) -> outq.  final: the span is Close()'s remainder.
+int writer_process(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bool final) {
+  m4g_ctx *c = w->ctx;
+  const Params &p = c->p;
+  HIP_TRY(hipSetDevice(w->device));
+  if (!final && bs != 0 && blocks_one_launch_ok(p, len, bs)) {
+    // match finding and encoding in one pass over device memory
+    BlocksHook hook;
+    const size_t nblocks = (len + bs - 1) / bs;
+    uint64_t bound = 0;
+    for (size_t b = 0; b < nblocks; b++) bound += std::min(bs, len - b * bs) / (size_t)p.min_length + 2;
+    if (w->format == M4G_FORMAT_BROTLI) {
+      const size_t nruns = len / K5_HUGE + nblocks + 64;
+      if (int rc = writer_reserve_brotli(w, nblocks, bound, nruns)) return rc;
+      hook.d_long_runs = w->d_runs;
+      hook.d_n_long = w->d_nruns;
+      hook.long_cap = (uint32_t)(w->runs_cap - 1);
+    }
+    hook.fn = [w](const uint8_t *d_src, const Job *d_blocks, const std::vector<uint64_t> &lens, const m4g_match *d_out,
+                  const uint64_t *d_off, uint64_t nmatches, hipStream_t st) -> int {
+      if (w->format == M4G_FORMAT_BROTLI)
+        if (int rc = writer_reserve_brotli(w, lens.size(), nmatches, 0)) return rc; // (a span of a longer call)
+      return writer_encode(w, d_src, d_blocks, lens, d_out, d_off, nmatches, st, false);
+    };
+    const int64_t r = find_blocks_impl(c, span, len, bs, nullptr, 0, nullptr, &hook);
+    return r < 0 ? (int)r : M4G_OK;
+  }
+  // one block, tiny blocks, or the remainder: Match lists over the host, then the same encoder
+  const size_t bs_eff = bs ? bs : std::max<size_t>(len, 1);
+  const size_t nlists = (len + bs_eff - 1) / bs_eff;
+  size_t need = 1;
+  for (size_t b = 0; b < nlists; b++) need += std::min(bs_eff, len - b * bs_eff) / (size_t)p.min_length + 2;
+  std::vector<m4g_match> ms(need);
+  std::vector<uint64_t> off(nlists + 1, 0);
+  if (len) {
+    const int64_t r = find_blocks_impl(c, span, len, bs_eff, ms.data(), ms.size(), off.data(), nullptr);
+    if (r < 0) return (int)r;
+  }
+  BlockUpload U;
+  if (int rc = U.init(w->device, span, len, final ? std::max<size_t>(len, 1) + 1 : bs_eff, ms.data(), off.data(), final))
+    return rc;
+  if (w->format == M4G_FORMAT_BROTLI) {
+    std::vector<LongRun> runs;
+    for (size_t j = 0; j < U.jobs.size(); j++) {
+      uint32_t pos = 0;
+      for (uint64_t k = U.off[j]; k < U.off[j + 1]; k++) {
+        if (ms[k].unmatched >= K5_HUGE) runs.push_back(LongRun{(uint32_t)j, pos, ms[k].unmatched, 0});
+        pos += ms[k].unmatched + ms[k].length;
+      }
+    }
+    if (int rc = writer_reserve_brotli(w, U.jobs.size(), U.nmatches, runs.size())) return rc;
+    const uint32_t nruns = (uint32_t)runs.size();
+    if (nruns) HIP_TRY(hipMemcpyAsync(w->d_runs, runs.data(), runs.size() * sizeof(LongRun), hipMemcpyHostToDevice, U.st));
+    HIP_TRY(hipMemcpyAsync(w->d_nruns, &nruns, 4, hipMemcpyHostToDevice, U.st));
+    HIP_TRY(hipStreamSynchronize(U.st));
+  }
+  return writer_encode(w, U.d_src, U.d_jobs, U.lens, U.d_m, U.d_off, U.nmatches, U.st, final);
+}
+
+int64_t writer_drain(m4g_writer *w, uint8_t *out, size_t out_cap) {
+  const size_t k = w->outq.size();
+  if (k > out_cap) return -(int64_t)(k + M4G_STREAM_NEEDED_BIAS);
+  if (k) std::memcpy(out, w->outq.data(), k);
+  w->outq.clear();
+  return (int64_t)k;
+}
+} // namespace
+
+extern "C" int m4g_writer_create(const m4g_params *params, int device, int format, size_t block_size,
+                                 uint32_t gzip_mtime, m4g_writer **out) {
+  if (!out) return fail(M4G_ERR_BAD_PARAM, "out is NULL");
+  *out = nullptr;
+  if (format != M4G_FORMAT_BROTLI && format != M4G_FORMAT_FLATE && format != M4G_FORMAT_GZIP)
+    return fail(M4G_ERR_BAD_PARAM, "unknown format");
+  if (block_size >= ((size_t)1 << 30)) return fail(M4G_ERR_TOO_LARGE, "block_size must stay below 2^30");
+  m4g_ctx *ctx = nullptr;
+  if (int rc = m4g_create(params, device, &ctx)) return rc;
+  if (format == M4G_FORMAT_BROTLI && ctx->p.min_length < 2) {
+    m4g_destroy(ctx);
+    return fail(M4G_ERR_BAD_PARAM, "the brotli encoder needs MinLength >= 2 (no copy length code for 1)");
+  }
+  m4g_writer *w = new m4g_writer();
+  w->ctx = ctx;
+  w->device = device;
+  w->format = format;
+  w->bs = block_size;
+  w->mtime = gzip_mtime;
+  if (hipEventCreate(&w->e0) != hipSuccess || hipEventCreate(&w->e1) != hipSuccess) {
+    m4g_writer_destroy(w);
+    return fail(M4G_ERR_HIP, "hipEventCreate failed");
+  }
+  *out = w;
+  return M4G_OK;
+}
+
+extern "C" void m4g_writer_destroy(m4g_writer *w) {
+  if (!w) return;
+  (void)hipSetDevice(w->device);
+  w->eb.release();
+  w->fb.release();
+  (void)hipFree(w->d_histos);
+  (void)hipFree(w->d_codes);
+  (void)hipFree(w->d_runs);
+  (void)hipFree(w->d_nruns);
+  if (w->e0) (void)hipEventDestroy(w->e0);
+  if (w->e1) (void)hipEventDestroy(w->e1);
+  m4g_destroy(w->ctx);
+  delete w;
+}
+
+extern "C" int m4g_writer_reset(m4g_writer *w) {
+  if (!w) return fail(M4G_ERR_BAD_PARAM, "writer is NULL");
+  w->inbuf.clear();
+  w->outq.clear();
+  w->wrote_header = false;
+  w->pend_byte = 0;
+  w->pend_bits = 0;
+  w->carry = GzipCarry();
+  return m4g_reset(w->ctx);
+}
+
+extern "C" int64_t m4g_writer_write(m4g_writer *w, const uint8_t *src, size_t n, uint8_t *out, size_t out_cap) {
+  if (!w || (!src && n) || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (n >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "at most 2 GiB per Write");
+  if (w->bs == 0) { // each Write is one block (matchfinder.go:64-66)
+    if (int rc = writer_process(w, src, n, 0, false)) return rc;
+    return writer_drain(w, out, out_cap);
+  }
+  // matchfinder.go:68-78: append, encode every full block, keep the rest
+  const uint8_t *span = src;
+  size_t avail = n;
+  if (!w->inbuf.empty()) {
+    const size_t blocks = (w->inbuf.size() + n) / w->bs;
+    if (blocks == 0) { // still no full block
+      w->inbuf.insert(w->inbuf.end(), src, src + n);
+      return writer_drain(w, out, out_cap);
+    }
+    // the pending bytes and the new ones up to the last block boundary, contiguous
+    const size_t take = blocks * w->bs - w->inbuf.size();
+    w->inbuf.insert(w->inbuf.end(), src, src + take);
+    if (int rc = writer_process(w, w->inbuf.data(), w->inbuf.size(), w->bs, false)) return rc;
+    w->inbuf.clear();
+    span = src + take;
+    avail = n - take;
+  }
+  const size_t full = (avail / w->bs) * w->bs;
+  if (full)
+    if (int rc = writer_process(w, span, full, w->bs, false)) return rc;
+  w->inbuf.insert(w->inbuf.end(), span + full, span + avail);
+  return writer_drain(w, out, out_cap);
+}
+
+extern "C" int64_t m4g_writer_close(m4g_writer *w, uint8_t *out, size_t out_cap) {
+  if (!w || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (!w->closed_pending) {
+    if (int rc = writer_process(w, w->inbuf.data(), w->inbuf.size(), w->bs, true)) return rc; // matchfinder.go:89-93
+    w->inbuf.clear();
+    w->closed_pending = true;
+  }
+  const int64_t r = writer_drain(w, out, out_cap);
+  if (r >= 0) w->closed_pending = false;
+  return r;
 }

@@ -39,7 +39,8 @@ EXPORTS = [
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
     "m4g_batch_status", "m4g_batch_run_device_noalloc",
-    "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
+    "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
+    "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
 ]
 
 _LIB = None
@@ -113,6 +114,15 @@ def lib():
         L.m4g_flate_encode_blocks.restype = ctypes.c_int64
         L.m4g_brotli_encode_blocks.argtypes = [ctypes.c_int, vp, sz, sz, vp, vp, vp, sz]
         L.m4g_brotli_encode_blocks.restype = ctypes.c_int64
+        L.m4g_writer_create.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.c_int, sz, ctypes.c_uint32,
+                                        ctypes.POINTER(vp)]
+        L.m4g_writer_write.argtypes = [vp, vp, sz, vp, sz]
+        L.m4g_writer_write.restype = ctypes.c_int64
+        L.m4g_writer_close.argtypes = [vp, vp, sz]
+        L.m4g_writer_close.restype = ctypes.c_int64
+        L.m4g_writer_reset.argtypes = [vp]
+        L.m4g_writer_destroy.argtypes = [vp]
+        L.m4g_writer_destroy.restype = None
         L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
@@ -432,6 +442,57 @@ class BatchPlan:
             raise M4GError(f"m4g_batch_flate_encode: stream_cap too small, need {-r - STREAM_NEEDED_BIAS}")
         return ((int(r) if out is not None else buf[:r].tobytes()), [float(ms[k]) for k in range(3)],
                 kinds[:nchunks].copy())
+
+
+FORMAT_BROTLI, FORMAT_FLATE, FORMAT_GZIP = 0, 1, 2
+
+
+class GPUWriter:
+    """``matchfinder.Writer`` (matchfinder/matchfinder.go:44-103) with BOTH plug-ins on the GPU (m4g_writer):
+    MatchFinder = matchfinder.M4{**m4_fields}, Encoder = brotli.Encoder / flate.NewEncoder() / flate.NewGZIPEncoder().
+    ``Dest`` needs a ``write`` method; Write / Close / Reset as in the reference."""
+
+    def __init__(self, Dest, format: int = FORMAT_BROTLI, BlockSize: int = 1 << 16, mtime: int = 0, device: int = 0,
+                 **m4_fields):
+        self.Dest = Dest
+        self.BlockSize = BlockSize
+        h = ctypes.c_void_p()
+        p = _params(m4_fields.get("MaxDistance", 0), m4_fields.get("MinLength", 0), m4_fields.get("HashLen", 0),
+                    m4_fields.get("TableBits", 0), m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
+        _check(lib().m4g_writer_create(ctypes.byref(p), device, format, BlockSize, mtime, ctypes.byref(h)),
+               "m4g_writer_create")
+        self._h = h
+        self._buf = np.zeros(1 << 20, dtype=np.uint8)
+
+    def _emit(self, call):
+        r = call(self._buf)
+        if r < -STREAM_NEEDED_BIAS:  # the output is kept inside: fetch it with a buffer that is large enough
+            self._buf = np.zeros(-r - STREAM_NEEDED_BIAS + 4096, dtype=np.uint8)
+            r = call(self._buf, again=True)
+        _check(r, "m4g_writer")
+        if r > 0:
+            self.Dest.write(self._buf[:r].tobytes())
+
+    def Write(self, p) -> int:
+        a = _as_u8(p)
+
+        def call(buf, again=False):
+            return lib().m4g_writer_write(self._h, None if again or not a.size else a.ctypes.data, 0 if again else a.size,
+                                          buf.ctypes.data, buf.size)
+        self._emit(call)
+        return a.size
+
+    def Close(self):
+        self._emit(lambda buf, again=False: lib().m4g_writer_close(self._h, buf.ctypes.data, buf.size))
+
+    def Reset(self, newDest):
+        _check(lib().m4g_writer_reset(self._h), "m4g_writer_reset")
+        self.Dest = newDest
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().m4g_writer_destroy(self._h)
+            self._h = None
 
 
 def brotli_compress(data, block_size: int = 1 << 16, device: int = 0, **m4_fields) -> bytes:

@@ -336,6 +336,40 @@ int64_t m4g_flate_encode_blocks(int device, const uint8_t *src, size_t n, size_t
                                 int gzip, uint32_t gzip_mtime, uint8_t *stream_out,
                                 size_t stream_cap, uint8_t *kinds_out);
 
+/* Replaces: matchfinder.Writer (matchfinder/matchfinder.go:44-103) -- the type
+ * brotli.NewWriterV2, flate.NewWriter and flate.NewGZIPWriter return and the
+ * reference's tests build by hand -- with BOTH of its plug-ins on the GPU:
+ *   MatchFinder = &matchfinder.M4{params}                       (m4.go)
+ *   Encoder     = &brotli.Encoder{}            M4G_FORMAT_BROTLI (encoder.go)
+ *                 flate.NewEncoder()           M4G_FORMAT_FLATE  (flate/huffman_bit_writer.go)
+ *                 flate.NewGZIPEncoder()       M4G_FORMAT_GZIP   (flate/gzip.go; gzip_mtime for time.Now())
+ *   BlockSize   = block_size (0: every Write is one block, matchfinder.go:64-66)
+ * m4g_writer_write = Writer.Write: appends to the pending input, encodes every
+ * full block, keeps the rest (lines 59-79); m4g_writer_close = Writer.Close: the
+ * remainder, possibly empty, as the last block (lines 89-93); m4g_writer_reset
+ * = Writer.Reset (lines 95-103).  Where the reference hands bytes to Dest.Write,
+ * these calls return them in `out`: exactly the bytes the reference's Writer has
+ * written after the same sequence of calls (whole bytes; the encoder's pending
+ * bits stay inside, bitwriter.go:11-17).  A call whose blocks qualify for the
+ * one-launch path of m4g_find_matches_blocks (two or more blocks of >= 3847
+ * bytes) finds the matches and encodes without moving Match lists or bytes over
+ * PCIe a second time.  If out_cap is too small the call returns -(needed +
+ * M4G_STREAM_NEEDED_BIAS) with the input consumed and the output kept: call
+ * again with n = 0 (write) or simply again (close) and a larger buffer.
+ * flate formats: M4G_ERR_TOKEN_RANGE where the reference panics (a match longer
+ * than 258 bytes, flate/token.go:59-71); the writer is then unusable until
+ * m4g_writer_reset.  One thread at a time per writer. */
+#define M4G_FORMAT_BROTLI 0
+#define M4G_FORMAT_FLATE 1
+#define M4G_FORMAT_GZIP 2
+typedef struct m4g_writer m4g_writer;
+int m4g_writer_create(const m4g_params *params, int device, int format, size_t block_size,
+                      uint32_t gzip_mtime, m4g_writer **out);
+int64_t m4g_writer_write(m4g_writer *w, const uint8_t *src, size_t n, uint8_t *out, size_t out_cap);
+int64_t m4g_writer_close(m4g_writer *w, uint8_t *out, size_t out_cap);
+int m4g_writer_reset(m4g_writer *w);
+void m4g_writer_destroy(m4g_writer *w);
+
 /* Kernel-side outcome of the plan's most recent m4g_batch_run_device[_codes]
  * call.  Those calls only enqueue work and return before it runs, so conditions
  * the kernels detect cannot come back through their return value: this call
