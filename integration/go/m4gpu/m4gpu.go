@@ -21,6 +21,7 @@ package m4gpu
 import "C"
 
 import (
+	"io"
 	"runtime"
 	"unsafe"
 
@@ -253,4 +254,96 @@ func (q *M4) BrotliCompress(data []byte, blockSize int) []byte {
 		fail("m4g_brotli_encode_blocks", C.int(n))
 	}
 	return out[:n]
+}
+
+// Writer is matchfinder.Writer (matchfinder/matchfinder.go:44-103) with the match finder and the encoder on the
+// GPU (m4g_writer_*): an io.WriteCloser with Reset.
+type Writer struct {
+	Dest io.Writer
+	w    *C.m4g_writer
+	buf  []byte
+	err  error
+}
+
+const (
+	FormatBrotli = 0 // Encoder: &brotli.Encoder{}
+	FormatFlate  = 1 // Encoder: flate.NewEncoder()
+	FormatGZIP   = 2 // Encoder: flate.NewGZIPEncoder()
+)
+
+func newWriter(dst io.Writer, q M4, format, blockSize int, mtime uint32) *Writer {
+	p := q.params()
+	var h *C.m4g_writer
+	if rc := C.m4g_writer_create(&p, C.int(q.Device), C.int(format), C.size_t(blockSize), C.uint32_t(mtime), &h); rc != 0 {
+		fail("m4g_writer_create", rc)
+	}
+	w := &Writer{Dest: dst, w: h, buf: make([]byte, 1<<20)}
+	runtime.SetFinalizer(w, func(w *Writer) { C.m4g_writer_destroy(w.w) })
+	return w
+}
+
+// NewBrotliWriter is &matchfinder.Writer{Dest: dst, MatchFinder: &matchfinder.M4{q's fields}, Encoder: &brotli.Encoder{},
+// BlockSize: blockSize} (brotli_test.go:626-649).
+func NewBrotliWriter(dst io.Writer, q M4, blockSize int) *Writer { return newWriter(dst, q, FormatBrotli, blockSize, 0) }
+
+func flateM4(level int) M4 {
+	chain, ok := map[int]int{5: 8, 6: 16, 7: 32}[level] // flate/writer.go:33-46
+	if !ok {
+		panic("m4gpu: flate levels 5..7 use matchfinder.M4")
+	}
+	return M4{MaxDistance: 1 << 15, HashLen: 5, ChainLength: chain, DistanceBitCost: 66}
+}
+
+// NewFlateWriter is flate.NewWriter(dst, level) for level 5, 6 or 7 (flate/writer.go:14-16).
+func NewFlateWriter(dst io.Writer, level int) *Writer {
+	return newWriter(dst, flateM4(level), FormatFlate, 1<<16, 0)
+}
+
+// NewGZIPWriter is flate.NewGZIPWriter(dst, level) for level 5, 6 or 7; mtime replaces time.Now() (flate/gzip.go:46).
+func NewGZIPWriter(dst io.Writer, level int, mtime uint32) *Writer {
+	return newWriter(dst, flateM4(level), FormatGZIP, 1<<16, mtime)
+}
+
+// emit hands what the library produced to Dest; output that did not fit is kept inside and fetched again.
+func (w *Writer) emit(call func(out *C.uint8_t, cap C.size_t, again bool) C.int64_t) {
+	n := call((*C.uint8_t)(unsafe.Pointer(&w.buf[0])), C.size_t(len(w.buf)), false)
+	if n < -C.M4G_STREAM_NEEDED_BIAS {
+		w.buf = make([]byte, int(-n)-C.M4G_STREAM_NEEDED_BIAS+4096)
+		n = call((*C.uint8_t)(unsafe.Pointer(&w.buf[0])), C.size_t(len(w.buf)), true)
+	}
+	if n < 0 {
+		fail("m4g_writer", C.int(n))
+	}
+	if n > 0 && w.err == nil {
+		_, w.err = w.Dest.Write(w.buf[:n])
+	}
+}
+
+// Write implements io.Writer (matchfinder.go:59-79).
+func (w *Writer) Write(p []byte) (int, error) {
+	if w.err != nil {
+		return 0, w.err
+	}
+	w.emit(func(out *C.uint8_t, cap C.size_t, again bool) C.int64_t {
+		if again || len(p) == 0 {
+			return C.m4g_writer_write(w.w, nil, 0, out, cap)
+		}
+		return C.m4g_writer_write(w.w, (*C.uint8_t)(unsafe.Pointer(&p[0])), C.size_t(len(p)), out, cap)
+	})
+	return len(p), w.err
+}
+
+// Close implements io.Closer (matchfinder.go:89-93).
+func (w *Writer) Close() error {
+	w.emit(func(out *C.uint8_t, cap C.size_t, again bool) C.int64_t { return C.m4g_writer_close(w.w, out, cap) })
+	return w.err
+}
+
+// Reset is matchfinder.Writer.Reset (matchfinder.go:95-103).
+func (w *Writer) Reset(newDest io.Writer) {
+	if rc := C.m4g_writer_reset(w.w); rc != 0 {
+		fail("m4g_writer_reset", rc)
+	}
+	w.err = nil
+	w.Dest = newDest
 }
