@@ -156,4 +156,56 @@ private:
   std::vector<Match> matches_;
 };
 
+// The same Writer with BOTH plug-ins on the GPU (m4g_writer_*): MatchFinder = M4{fields}, Encoder = brotli.Encoder
+// (M4G_FORMAT_BROTLI), flate.NewEncoder() (M4G_FORMAT_FLATE) or flate.NewGZIPEncoder() (M4G_FORMAT_GZIP).  Dest
+// receives the bytes the reference's Writer passes to Dest.Write after the same calls.
+template <class Dest> class GPUWriter {
+public:
+  Dest *dest = nullptr;
+
+  GPUWriter(Dest *d, const m4g_params &fields, int format, size_t blockSize, uint32_t gzipMtime = 0, int device = 0)
+      : dest(d), buf_(1 << 20) {
+    const int rc = m4g_writer_create(&fields, device, format, blockSize, gzipMtime, &w_);
+    if (rc != M4G_OK)
+      throw std::runtime_error(std::string("m4g_writer_create: ") + m4g_strerror(rc) + " (" + m4g_last_error() + ")");
+  }
+  ~GPUWriter() { m4g_writer_destroy(w_); }
+  GPUWriter(const GPUWriter &) = delete;
+  GPUWriter &operator=(const GPUWriter &) = delete;
+
+  // flate.NewWriter(dst, level) / flate.NewGZIPWriter(dst, level), level 5..7 (flate/writer.go:33-66)
+  static m4g_params flateFields(int level) {
+    m4g_params p{};
+    p.max_distance = 1 << 15;
+    p.hash_len = 5;
+    p.chain_length = level == 5 ? 8 : level == 6 ? 16 : 32;
+    p.distance_bit_cost = 66;
+    return p;
+  }
+
+  size_t Write(const uint8_t *p, size_t n) {
+    emit(m4g_writer_write(w_, p, n, buf_.data(), buf_.size()), true);
+    return n;
+  }
+  void Close() { emit(m4g_writer_close(w_, buf_.data(), buf_.size()), false); }
+  void Reset(Dest *newDest) {
+    const int rc = m4g_writer_reset(w_);
+    if (rc != M4G_OK) throw std::runtime_error(std::string("m4g_writer_reset: ") + m4g_strerror(rc));
+    dest = newDest;
+  }
+
+private:
+  void emit(int64_t r, bool writing) {
+    if (r < -(int64_t)M4G_STREAM_NEEDED_BIAS) { // kept inside: fetch it with a buffer that is large enough
+      buf_.resize((size_t)(-r - M4G_STREAM_NEEDED_BIAS) + 4096);
+      r = writing ? m4g_writer_write(w_, nullptr, 0, buf_.data(), buf_.size()) : m4g_writer_close(w_, buf_.data(), buf_.size());
+    }
+    if (r < 0)
+      throw std::runtime_error(std::string("m4g_writer: ") + m4g_strerror((int)r) + " (" + m4g_last_error() + ")");
+    if (r > 0) (*dest)(buf_.data(), (size_t)r);
+  }
+  m4g_writer *w_ = nullptr;
+  std::vector<uint8_t> buf_;
+};
+
 } // namespace matchfinder

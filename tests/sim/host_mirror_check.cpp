@@ -42,6 +42,39 @@ int main() {
       }
     }
   }
+  // the Writer with both plug-ins on the GPU: a brotli stream of those bytes written in ragged pieces and, after
+  // Reset, in one piece -- the same bytes either way (the Python tests compare such streams with the restated
+  // Writer); the flate encoder refuses this input as the reference does (matches longer than 258 bytes)
+  struct Sink {
+    std::vector<uint8_t> v;
+    void operator()(const uint8_t *p, size_t n) { v.insert(v.end(), p, p + n); }
+  } a, b, f;
+  m4g_params fields{};
+  fields.max_distance = 1 << 16;
+  matchfinder::GPUWriter<Sink> w(&a, fields, M4G_FORMAT_BROTLI, 8192);
+  w.Write(data.data(), 5);
+  w.Write(data.data() + 5, 20000);
+  w.Write(data.data() + 20005, data.size() - 20005);
+  w.Close();
+  w.Reset(&b);
+  w.Write(data.data(), data.size());
+  w.Close();
+  if (a.v.size() < 8 || (a.v[0] & 15) != 15 || a.v != b.v || a.v.size() > data.size() / 4) {
+    std::puts("FAIL writer");
+    return 1;
+  }
+  bool refused = false;
+  try {
+    matchfinder::GPUWriter<Sink> wf(&f, matchfinder::GPUWriter<Sink>::flateFields(6), M4G_FORMAT_GZIP, 8192, 42);
+    wf.Write(data.data(), data.size());
+    wf.Close();
+  } catch (const std::runtime_error &) {
+    refused = true;
+  }
+  if (!refused) {
+    std::puts("FAIL writer (token limits)");
+    return 1;
+  }
   std::puts("ok");
   return 0;
 }
