@@ -181,6 +181,46 @@ def flate_leg(host, n: int, chunks: int, dev, device_index: int, no_cpu: bool) -
     return res
 
 
+def writer_leg(host, nbytes: int, device_index: int) -> dict:
+    """matchfinder.Writer{M4, Encoder, BlockSize 1 << 16} over the first nbytes of the workload as ONE stream, host
+    memory in, host memory out (m4g_writer: match finding with the history carried from block to block AND the
+    encoder on the GPU): the reference tests' brotli writer (params G) and flate.NewGZIPWriter(level 6)."""
+    import gzip
+    from brotli_amd import m4
+    from oracle_lib import brotli_decompress  # (libbrotlidec, the stand-in for brotli.NewReader)
+
+    class Sink:
+        def __init__(self):
+            self.parts = []
+
+        def write(self, b):
+            self.parts.append(b)
+
+    res = {"stream_bytes_in": nbytes, "unit": "GB/s", "block_size": 1 << 16,
+           "sample": "one Write of the whole input from pageable memory + Close, second run on a warm writer; wall "
+                     "clock of the Python wrapper (H2D, K1-K4 per span, encoder kernels, host code building, D2H)"}
+    data = host[:nbytes]
+    for name, fmt, kw in (("brotli_G", m4.FORMAT_BROTLI, PARAM_SETS["G"]), ("gzip_level6", m4.FORMAT_GZIP, m4.flate_m4_params(6))):
+        try:
+            w = m4.GPUWriter(Sink(), fmt, 1 << 16, mtime=1, device=device_index, **kw)
+            w.Write(data[:8 << 20])
+            w.Close()
+            sink = Sink()
+            w.Reset(sink)
+            t0 = time.perf_counter()
+            w.Write(data)
+            w.Close()
+            dt = time.perf_counter() - t0
+            stream = b"".join(sink.parts)
+            back = brotli_decompress(stream, nbytes) if fmt == m4.FORMAT_BROTLI else gzip.decompress(stream)
+            res[name] = {"value": round(nbytes / dt / 1e9, 3), "ms": round(dt * 1e3, 1),
+                         "compression_ratio": round(nbytes / len(stream), 4), "decodes_to_input": back == data.tobytes()}
+            del w
+        except m4.M4GError as e:
+            res[name] = {"error": str(e)}
+    return res
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -211,6 +251,8 @@ def parse_args():
                     help="skip the m4g_batch_encode leg (Encoder pass 2 on the GPU, SURVEY 8f.2)")
     ap.add_argument("--flate-chunks", type=int, default=256,
                     help="chunks of the flate leg (M4 at flate level 6 + m4g_batch_flate_encode, SURVEY 8f.4); 0 = skip")
+    ap.add_argument("--writer-mib", type=int, default=256,
+                    help="MiB of the workload compressed as ONE stream by m4g_writer (matchfinder.Writer on the GPU); 0 = skip")
     ap.add_argument("--e2e-sample-chunks", type=int, default=512)
     ap.add_argument("--e2e-persistent-chunks", type=int, default=2048)
     return ap.parse_args()
@@ -553,6 +595,8 @@ def main():
         pin_out.close()
     if rank == 0 and world == 1 and args.flate_chunks > 0 and args.kind == "text" and not args.no_gpu_encode:
         out["gpu_flate"] = flate_leg(host, n, min(C, args.flate_chunks), dev, local_rank, args.no_cpu_baseline)
+    if rank == 0 and world == 1 and args.writer_mib > 0 and args.kind == "text" and not args.no_gpu_encode:
+        out["gpu_writer"] = writer_leg(host, min(n * C, args.writer_mib << 20), local_rank)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

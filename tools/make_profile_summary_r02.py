@@ -46,7 +46,7 @@ b = last_json(os.path.join(run, "bench.json"))
 bl, bd = last_json(os.path.join(run, "bench_log.json")), last_json(os.path.join(run, "bench_D.json"))
 for name, d in ((f"{tag}_bench.json", b), (f"{tag}_bench_log.json", bl), (f"{tag}_bench_D.json", bd)):
     json.dump(d, open(P(name), "w"))
-for f in ("kind_probe.log", "stream_probe.log", "hostbatch_probe.log"):
+for f in ("kind_probe.log", "stream_probe.log", "hostbatch_probe.log", "writer_probe.log", "compress_probe.log"):
     if os.path.exists(os.path.join(run, f)):
         shutil.copy(os.path.join(run, f), P(f"{tag}_{f}"))
 for key, fd, wd in (("text/G", "pmc_fetch", "pmc_write"), ("text/D", "pmc_fetch_D", "pmc_write_D"),
@@ -101,7 +101,7 @@ rows = [r for r in csv.DictReader(open(stats_file)) if "m4g" in r["Name"]]
 L = [f"# Round {tag[1:]} profile summary (1 x MI355X)\n",
      "Made by `tools/profile_run_r02.sh` + `tools/make_profile_summary_r02.py`.",
      "Trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2`",
-     "(4096 x 1 MiB synthetic text chunks, params G; the run also makes the gpu_encode leg, hence k6).",
+     "(4096 x 1 MiB synthetic text chunks, params G; the run also makes the gpu_encode, gpu_flate and gpu_writer legs, hence k6, k5f / k6f / k7 and the k1x / ks kernels of the streaming handle).",
      f"Raw: `profiles/{tag}_kernel_stats.csv`; bench line of the plain `python bench.py` run: `profiles/{tag}_bench.json`;",
      f"counter table: `profiles/{tag}_counters.md`; HBM-side bytes per input byte: `profiles/traffic.json`.\n",
      "| kernel | calls | avg ms | % |\n|---|---|---|---|"]
@@ -121,6 +121,14 @@ L.append(f"Encoder: CPU Encode (restated, one thread) {ce.get('s_per_GiB')} s pe
 L.append(f"Host-memory API (PCIe both ways): {e2e.get('value')} GB/s from pageable memory, {e2e.get('value_pinned')} from "
          f"m4g_host_alloc buffers (512 chunks, set-up included), {e2e.get('value_pinned_persistent')} on the persistent handle "
          f"({e2e.get('persistent_sample_chunks')} chunks).\n")
+gf, gw = b.get("gpu_flate", {}), b.get("gpu_writer", {})
+L.append(f"flate (level 6 M4 fields, {gf.get('chunks')} chunks as one gzip stream): match finding {gf.get('find_matches_value')} GB/s, "
+         f"m4g_batch_flate_encode {gf.get('encode_ms_total')} ms = {gf.get('encode_value')} GB/s (host codes {gf.get('encode_ms_host_codes')} ms, "
+         f"k6f {gf.get('encode_ms_k6f_tokens')} ms), ratio {gf.get('compression_ratio')}, inflates: {gf.get('gzip_stream_inflates_to_input')}, "
+         f"restated CPU encoder {gf.get('cpu_encode_s_per_GiB')} s per GiB.")
+L.append(f"m4g_writer (matchfinder.Writer on the GPU, ONE stream of {gw.get('stream_bytes_in')} bytes, 64 KiB blocks, pageable host memory "
+         f"in and out): brotli params G {gw.get('brotli_G')}, gzip level 6 {gw.get('gzip_level6')}; more: `profiles/{tag}_writer_probe.log`, "
+         f"two-call form: `profiles/{tag}_compress_probe.log`.\n")
 L.append("Other workloads (1024 x 1 MiB chunks, same run):\n")
 L.append(f"* low-entropy binary log, params G (BASELINE config 5): {bl['value']} GB/s, stage_ms {bl['stage_ms']}, ratio {bl['config']['compression_ratio']}, roofline.traffic {bl['roofline']['traffic']} GB")
 L.append(f"* text, params D (ChainLength 64, HashLen 5; BASELINE config 4): {bd['value']} GB/s, stage_ms {bd['stage_ms']}, ratio {bd['config']['compression_ratio']}, roofline.traffic {bd['roofline']['traffic']} GB")
