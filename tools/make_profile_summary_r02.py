@@ -42,6 +42,10 @@ def stats_of(sub):
 stats_file, ms4k = stats_of("trace")
 _, ms1k = stats_of("trace1k")
 shutil.copy(stats_file, P(f"{tag}_kernel_stats.csv"))
+try:
+    shutil.copy(stats_of("trace_legs")[0], P(f"{tag}_kernel_stats_legs.csv"))
+except Exception:
+    pass
 b = last_json(os.path.join(run, "bench.json"))
 bl, bd = last_json(os.path.join(run, "bench_log.json")), last_json(os.path.join(run, "bench_D.json"))
 for name, d in ((f"{tag}_bench.json", b), (f"{tag}_bench_log.json", bl), (f"{tag}_bench_D.json", bd)):
@@ -100,8 +104,8 @@ open(P(f"{tag}_counters.md"), "w").write("\n".join(T) + "\n")
 rows = [r for r in csv.DictReader(open(stats_file)) if "m4g" in r["Name"]]
 L = [f"# Round {tag[1:]} profile summary (1 x MI355X)\n",
      "Made by `tools/profile_run_r02.sh` + `tools/make_profile_summary_r02.py`.",
-     "Trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2`",
-     "(4096 x 1 MiB synthetic text chunks, params G; the run also makes the gpu_encode, gpu_flate and gpu_writer legs, hence k6, k5f / k6f / k7 and the k1x / ks kernels of the streaming handle).",
+     "Trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0`",
+     f"(4096 x 1 MiB synthetic text chunks, params G; the run also makes the gpu_encode leg, hence k6 and k5_histograms<true>; the kernels of the flate and writer legs, 256 chunks: `profiles/{tag}_kernel_stats_legs.csv`).",
      f"Raw: `profiles/{tag}_kernel_stats.csv`; bench line of the plain `python bench.py` run: `profiles/{tag}_bench.json`;",
      f"counter table: `profiles/{tag}_counters.md`; HBM-side bytes per input byte: `profiles/traffic.json`.\n",
      "| kernel | calls | avg ms | % |\n|---|---|---|---|"]

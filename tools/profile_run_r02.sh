@@ -16,7 +16,8 @@ step smoke   bash -c "timeout -k 10 120 python __graft_entry__.py smoke > $out/s
 step bench   bash -c "timeout -k 10 500 python bench.py > $out/bench.json 2> $out/bench.err"
 step log     bash -c "timeout -k 10 200 python bench.py --chunks 1024 --kind log --no-end-to-end --writer-mib 0 > $out/bench_log.json 2>> $out/bench.err"
 step D       bash -c "timeout -k 10 300 python bench.py --chunks 1024 --params D --no-end-to-end --flate-chunks 0 --writer-mib 0 > $out/bench_D.json 2>> $out/bench.err"
-step trace   bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2 > $out/trace.log 2>&1"
+step trace   bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0 > $out/trace.log 2>&1"
+step tracel  bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_legs -- python3 bench.py --chunks 256 --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --verify-chunks 0 > $out/trace_legs.log 2>&1"
 step trace1k bash -c "timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1k -- $B1K > $out/trace1k.log 2>&1"
 pmc fetch "" FETCH_SIZE
 pmc write "" WRITE_SIZE
