@@ -24,6 +24,7 @@
 // Literal runs of 64 bytes or more are written by the whole wave (64 literals
 // per step, positions from a wave prefix sum of their code lengths).
 #pragma once
+#include <type_traits>
 
 namespace m4g {
 
@@ -57,13 +58,24 @@ __constant__ const K6LenTables kK6Len = k6_len_tables();
 // word = code bits (already bit-reversed for LSB-first writing) | depth << 16.
 constexpr int K6_TAB = 1024;
 
-// LSB-first bit appender of one thread, merged into the stream with atomic OR.
+// Where the bits of one iteration (K6_THREADS matches) go.  The span of an iteration is contiguous in the stream
+// (bit positions are prefix sums), so it is assembled in an LDS window first and then stored with plain, coalesced
+// word stores; only the first and the last word of the span, which neighbours share, are merged into the zeroed
+// stream with atomic OR.  A span larger than the window (long literal runs) goes to the stream word by word with
+// atomic OR, as every write did before (measured: 2.9 GB read + 4.0 GB written per GiB of input at 1 TB/s).
+constexpr int K6_WIN_WORDS = 2048; // 64 Kbit: ~4x the span of 512 matches of text
+struct K6Sink {
+  uint32_t *base;  // window (LDS) or stream (global)
+  uint64_t bit0;   // stream bit position of base's bit 0 (a multiple of 32)
+};
+
+// LSB-first bit appender of one thread.
 struct K6Out {
   uint32_t *w;   // next word
   uint64_t acc;  // pending bits (the low n)
   uint32_t n;
-  __device__ __forceinline__ void start(uint32_t *words, uint64_t bitpos) {
-    w = words + (bitpos >> 5);
+  __device__ __forceinline__ void start(const K6Sink &s, uint64_t bitpos) {
+    w = s.base + ((bitpos - s.bit0) >> 5);
     acc = 0;
     n = (uint32_t)(bitpos & 31); // the bits below belong to somebody else: zero here, harmless to OR
   }
@@ -81,11 +93,33 @@ struct K6Out {
   }
 };
 // one code of up to 32 bits at an arbitrary bit position
-__device__ __forceinline__ void k6_or_at(uint32_t *words, uint64_t bitpos, uint32_t v) {
+__device__ __forceinline__ void k6_or_at(const K6Sink &s, uint64_t bitpos, uint32_t v) {
   const uint64_t x = (uint64_t)v << (bitpos & 31);
-  uint32_t *w = words + (bitpos >> 5);
+  uint32_t *w = s.base + ((bitpos - s.bit0) >> 5);
   if ((uint32_t)x) atomicOr(w, (uint32_t)x);
   if ((uint32_t)(x >> 32)) atomicOr(w + 1, (uint32_t)(x >> 32));
+}
+__device__ __forceinline__ void k6_or_at(uint32_t *words, uint64_t bitpos, uint32_t v) {
+  k6_or_at(K6Sink{words, 0}, bitpos, v);
+}
+
+// The window of an iteration whose bits are [s0, s1): chosen before the writes ...
+__device__ __forceinline__ bool k6_span_fits(uint64_t s0, uint64_t s1) {
+  return s1 - (s0 & ~31ull) <= (uint64_t)K6_WIN_WORDS * 32;
+}
+// ... and stored after them (all threads; a barrier separates the writes from this).  Leaves the window zero.
+__device__ __forceinline__ void k6_store_window(uint32_t *win, uint32_t *words, uint64_t s0, uint64_t s1, int tid, int nthreads) {
+  const uint64_t w0 = s0 >> 5, w1 = (s1 + 31) >> 5; // words [w0, w1) hold bits of the span
+  for (uint64_t k = w0 + tid; k < w1; k += nthreads) {
+    const uint32_t v = win[k - w0];
+    win[k - w0] = 0;
+    const bool shared_word = (k == w0 && (s0 & 31)) || (k == w1 - 1 && (s1 & 31));
+    if (shared_word) {
+      if (v) atomicOr(words + k, v);
+    } else {
+      words[k] = v;
+    }
+  }
 }
 
 __global__ __launch_bounds__(K6_THREADS) void k6_emit_bodies(
@@ -94,6 +128,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_emit_bodies(
     const uint32_t *__restrict__ tables /* K6_TAB words per job */, const uint64_t *__restrict__ body_pos /* per job */,
     uint32_t *__restrict__ words, uint64_t *__restrict__ body_bits /* per job: bits written (for the host's check) */) {
   __shared__ uint32_t tab[K6_TAB];
+  __shared__ uint32_t win[K6_WIN_WORDS + 2];
   __shared__ uint32_t wadv[2][K6_WAVES], wbits[2][K6_WAVES];
   __shared__ uint32_t cpos[2];
   __shared__ uint64_t cbit[2];
@@ -106,6 +141,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_emit_bodies(
   const uint8_t *src = src_base + J.src_off;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   for (int k = tid; k < K6_TAB; k += K6_THREADS) tab[k] = tables[(size_t)job * K6_TAB + k];
+  for (int k = tid; k < K6_WIN_WORDS + 2; k += K6_THREADS) win[k] = 0;
   if (tid == 0) {
     cpos[0] = J.start;
     cbit[0] = body_pos[job];
@@ -163,15 +199,23 @@ __global__ __launch_bounds__(K6_THREADS) void k6_emit_bodies(
     }
     if (lane == 63) wbits[par][wid] = binc;
     __syncthreads();
-    uint64_t bpos = cbit[par];
-    for (int w = 0; w < wid; w++) bpos += wbits[par][w];
+    const uint64_t s0 = cbit[par];
+    uint64_t bpos = s0, s1 = s0;
+    for (int w = 0; w < K6_WAVES; w++) {
+      if (w < wid) bpos += wbits[par][w];
+      s1 += wbits[par][w];
+    }
     if (tid == K6_THREADS - 1) cbit[par ^ 1] = bpos + binc;
     bpos += binc - total; // where this match's bits begin
+    const bool windowed = k6_span_fits(s0, s1); // workgroup-uniform
+    // (two instantiations, so that the window's atomics are LDS instructions and the stream's are global ones)
+    auto emit = [&](auto to_window) {
+    const K6Sink sink = decltype(to_window)::value ? K6Sink{win, s0 & ~31ull} : K6Sink{words, 0};
 
     // ---- write (encoder.go:131-151) ----
     if (j < n) {
       K6Out o;
-      o.start(words, bpos);
+      o.start(sink, bpos);
       o.put(tc >> 16, tc & 0xFFFFu);
       if (ien) o.put(ien, un - kK6Len.ins_base[ic]);
       if (cen) o.put(cen, len - kK6Len.copy_base[cc]);
@@ -182,7 +226,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_emit_bodies(
         }
       o.finish();
       if (has_dist) {
-        o.start(words, bpos + head_bits + lit_bits);
+        o.start(sink, bpos + head_bits + lit_bits);
         o.put(td >> 16, td & 0xFFFFu);
         if (c.n_extra) o.put(c.n_extra, c.extra_bits);
         o.finish();
@@ -201,9 +245,16 @@ __global__ __launch_bounds__(K6_THREADS) void k6_emit_bodies(
           const uint32_t v = __shfl_up(pin, o);
           if (lane >= o) pin += v;
         }
-        if (t >> 16) k6_or_at(words, p + pin - (t >> 16), t & 0xFFFFu);
+        if (t >> 16) k6_or_at(sink, p + pin - (t >> 16), t & 0xFFFFu);
         p += __shfl(pin, 63);
       }
+    }
+    };
+    if (windowed) emit(std::true_type{});
+    else emit(std::false_type{});
+    if (windowed) { // (the next iteration's two barriers come before its first write into the window)
+      __syncthreads();
+      k6_store_window(win, words, s0, s1, tid, K6_THREADS);
     }
   }
   __syncthreads();

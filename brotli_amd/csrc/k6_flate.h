@@ -22,6 +22,7 @@
 //                     block's bytes are copied to their byte-aligned place.
 // Literal runs of 64 bytes or more are counted / written by the whole wave.
 #pragma once
+#include <type_traits>
 
 namespace m4g {
 
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(KF_THREADS) void k6f_flate_bodies(
     const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ tables, const uint64_t *__restrict__ body_pos,
     const uint32_t *__restrict__ mode, uint32_t *__restrict__ words, uint64_t *__restrict__ body_bits) {
   __shared__ uint32_t tab[KF_TAB];
+  __shared__ uint32_t win[K6_WIN_WORDS + 2]; // the bits of one iteration, assembled here (k6_encode.h)
   __shared__ uint32_t wadv[2][KF_WAVES], wbits[2][KF_WAVES];
   __shared__ uint32_t cpos[2];
   __shared__ uint64_t cbit[2];
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(KF_THREADS) void k6f_flate_bodies(
   const uint32_t n = (uint32_t)(out_off[job + 1] - o0);
   const uint32_t *rec = matches + o0 * 3;
   for (int k = tid; k < KF_TAB; k += KF_THREADS) tab[k] = tables[(size_t)job * KF_TAB + k];
+  for (int k = tid; k < K6_WIN_WORDS + 2; k += KF_THREADS) win[k] = 0;
   if (tid == 0) {
     cpos[0] = J.start;
     cbit[0] = pos0;
@@ -232,22 +235,30 @@ __global__ __launch_bounds__(KF_THREADS) void k6f_flate_bodies(
     }
     if (lane == 63) wbits[par][wid] = binc;
     __syncthreads();
-    uint64_t bpos = cbit[par];
-    for (int w = 0; w < wid; w++) bpos += wbits[par][w];
+    const uint64_t s0 = cbit[par];
+    uint64_t bpos = s0, s1 = s0;
+    for (int w = 0; w < KF_WAVES; w++) {
+      if (w < wid) bpos += wbits[par][w];
+      s1 += wbits[par][w];
+    }
     if (tid == KF_THREADS - 1) cbit[par ^ 1] = bpos + binc;
     bpos += binc - total; // where this match's bits begin
+    const bool windowed = k6_span_fits(s0, s1); // workgroup-uniform
+    // (two instantiations, so that the window's atomics are LDS instructions and the stream's are global ones)
+    auto emit = [&](auto to_window) {
+    const K6Sink sink = decltype(to_window)::value ? K6Sink{win, s0 & ~31ull} : K6Sink{words, 0};
 
     // ---- write: literals, length code + extra, offset code + extra ----
     if (j < n) {
       K6Out o;
       if (!longrun) {
-        o.start(words, bpos);
+        o.start(sink, bpos);
         for (uint32_t k = 0; k < un; k++) {
           const uint32_t t = tab[src[ls + k]];
           o.put(t >> 16, t & 0xFFFFu);
         }
       } else {
-        o.start(words, bpos + lit_bits); // the wave writes the run below
+        o.start(sink, bpos + lit_bits); // the wave writes the run below
       }
       if (has) {
         o.put(tl >> 16, tl & 0xFFFFu);
@@ -269,9 +280,16 @@ __global__ __launch_bounds__(KF_THREADS) void k6f_flate_bodies(
           const uint32_t v = __shfl_up(pin, o);
           if (lane >= o) pin += v;
         }
-        if (t >> 16) k6_or_at(words, p + pin - (t >> 16), t & 0xFFFFu);
+        if (t >> 16) k6_or_at(sink, p + pin - (t >> 16), t & 0xFFFFu);
         p += __shfl(pin, 63);
       }
+    }
+    };
+    if (windowed) emit(std::true_type{});
+    else emit(std::false_type{});
+    if (windowed) { // (the next iteration's two barriers come before its first write into the window)
+      __syncthreads();
+      k6_store_window(win, words, s0, s1, tid, KF_THREADS);
     }
   }
   __syncthreads();
