@@ -1763,6 +1763,13 @@ struct HostLane {
   hipStream_t st_in = nullptr, st_run = nullptr, st_out = nullptr;
   std::vector<hipEvent_t> ev_in, ev_run;
   // per run
+  // m4g_hostbatch_compress (allocated at its first call)
+  CodeRec *d_codes = nullptr;         // K5's per-match records, indexed like d_out
+  Job *d_cjobs = nullptr;             // one job per chunk for the encoder kernels (share entries)
+  Job *h_cjobs = nullptr;             // pinned image of d_cjobs
+  EncBuffers eb;
+  FlateBuffers fb;
+  hipEvent_t ev_enc[2] = {nullptr, nullptr};
   std::vector<size_t> chunks;         // global indices of this lane's chunks
   std::vector<uint64_t> off, cap_off; // local input offsets / worst-case output slots
   std::vector<uint64_t> count_off;    // local exclusive prefix of match counts (after phase 1)
@@ -1790,6 +1797,12 @@ void hostlane_free(HostLane &L) {
   if (L.h_out_off) (void)hipHostFree(L.h_out_off);
   if (L.h_err) (void)hipHostFree(L.h_err);
   if (L.h_histos) (void)hipHostFree(L.h_histos);
+  (void)hipFree(L.d_codes);
+  (void)hipFree(L.d_cjobs);
+  if (L.h_cjobs) (void)hipHostFree(L.h_cjobs);
+  L.eb.release();
+  L.fb.release();
+  for (auto &e : L.ev_enc) if (e) (void)hipEventDestroy(e);
   for (auto &e : L.ev_in) if (e) (void)hipEventDestroy(e);
   for (auto &e : L.ev_run) if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : {L.st_in, L.st_run, L.st_out})
@@ -2026,6 +2039,119 @@ extern "C" int64_t m4g_hostbatch_run(m4g_hostbatch *h, const uint8_t *base, cons
   for (auto &L : h->lanes)
     if (L.result != M4G_OK) return fail((int)L.result, "m4g_hostbatch_run: copying the Match lists back failed");
   return M4G_OK;
+}
+
+// Chunks in host memory -> ONE compressed stream in host memory (include/m4g.h).  Slices as in m4g_hostbatch_run:
+// uploads on st_in, K1..K5 of every slice back to back on st_run; the encoder of a finished slice (host code
+// building, K6 / k5f + k6f, D2H of its piece of the stream) runs on st_out while later slices still compute.  The
+// Match lists stay on the device: the link carries 1 byte in and ~0.35 bytes out per input byte instead of 1 + 1.
+extern "C" int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t gzip_mtime, const uint8_t *base,
+                                          const uint64_t *chunk_off, size_t nchunks, uint8_t *stream_out, size_t stream_cap) {
+  if (!h || !chunk_off || (!base && nchunks) || (!stream_out && stream_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (format != M4G_FORMAT_BROTLI && format != M4G_FORMAT_FLATE && format != M4G_FORMAT_GZIP)
+    return fail(M4G_ERR_BAD_PARAM, "unknown format");
+  if (h->lanes.size() != 1)
+    return fail(M4G_ERR_BAD_PARAM, "m4g_hostbatch_compress: one device per stream (make the handle with one device)");
+  if (nchunks > h->max_chunks) return fail(M4G_ERR_TOO_LARGE, "nchunks above the handle's max_chunks");
+  if (format == M4G_FORMAT_BROTLI && h->p.min_length < 2)
+    return fail(M4G_ERR_BAD_PARAM, "the brotli encoder needs MinLength >= 2 (no copy length code for 1)");
+  for (size_t c = 0; c < nchunks; c++) {
+    if (chunk_off[c + 1] < chunk_off[c]) return fail(M4G_ERR_BAD_PARAM, "chunk_off not ascending");
+    if (chunk_off[c + 1] - chunk_off[c] > h->max_chunk_bytes)
+      return fail(M4G_ERR_TOO_LARGE, "chunk larger than the handle's max_chunk_bytes");
+  }
+  HostLane &L = h->lanes[0];
+  HIP_TRY(hipSetDevice(L.device));
+  const bool brotli = format == M4G_FORMAT_BROTLI;
+  const size_t cap = L.share * (h->max_chunk_bytes / (size_t)h->p.min_length + 2);
+  if (brotli && !L.d_codes && hipMalloc(&L.d_codes, cap * sizeof(CodeRec)) != hipSuccess)
+    return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the per-match code records failed");
+  if (!L.d_cjobs) {
+    if (hipMalloc(&L.d_cjobs, L.share * sizeof(Job)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&L.h_cjobs), L.share * sizeof(Job), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&L.ev_enc[0]) != hipSuccess || hipEventCreate(&L.ev_enc[1]) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "allocating the encoder's job list failed");
+  }
+  const size_t n = nchunks;
+  L.off.assign(n + 1, 0);
+  L.cap_off.assign(n + 1, 0);
+  for (size_t k = 0; k < n; k++) {
+    const uint64_t len = chunk_off[k + 1] - chunk_off[k];
+    L.off[k + 1] = L.off[k] + len;
+    L.cap_off[k + 1] = L.cap_off[k] + len / (size_t)h->p.min_length + 2;
+    Job J{};
+    J.src_off = L.off[k];
+    J.len = (uint32_t)len;
+    L.h_cjobs[k] = J;
+  }
+  // enqueue: job list, then per slice its upload and its kernels
+  if (n) HIP_TRY(hipMemcpyAsync(L.d_cjobs, L.h_cjobs, n * sizeof(Job), hipMemcpyHostToDevice, L.st_in));
+  const size_t nsl = (n + L.slice - 1) / L.slice;
+  for (size_t s = 0; s < nsl; s++) {
+    const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice), nc = k1 - k0;
+    if (L.off[k1] > L.off[k0])
+      HIP_TRY(hipMemcpyAsync(L.d_src + L.off[k0], base + chunk_off[k0], L.off[k1] - L.off[k0], hipMemcpyHostToDevice, L.st_in));
+    HIP_TRY(hipEventRecord(L.ev_in[s], L.st_in));
+    HIP_TRY(hipStreamWaitEvent(L.st_run, L.ev_in[s], 0));
+    const int rc = m4g_batch_run_device_codes(
+        L.plan, L.d_src, L.off.data() + k0, nc, L.d_out + L.cap_off[k0], L.d_out_off + s * (L.slice + 1),
+        L.cap_off[k1] - L.cap_off[k0], brotli ? L.d_histos + k0 : nullptr,
+        brotli ? reinterpret_cast<m4g_code *>(L.d_codes + L.cap_off[k0]) : nullptr, L.st_run);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(L.h_err + s, L.plan->W.d_errors, 4, hipMemcpyDeviceToHost, L.st_run));
+    HIP_TRY(hipEventRecord(L.ev_run[s], L.st_run));
+  }
+  // encode slice after slice; the stream continues at bit granularity
+  auto drain = [&]() {
+    for (hipStream_t st : {L.st_in, L.st_run, L.st_out}) (void)hipStreamSynchronize(st);
+  };
+  uint64_t bytes = 0; // whole bytes of the stream so far
+  unsigned pend_bits = 0;
+  uint8_t pend_byte = 0;
+  GzipCarry carry;
+  for (size_t s = 0; s < std::max<size_t>(nsl, 1); s++) {
+    const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice);
+    const bool first = s == 0, last = s + 1 >= nsl;
+    std::vector<uint64_t> lens;
+    for (size_t k = k0; k < k1; k++) lens.push_back(L.off[k + 1] - L.off[k]);
+    if (nsl) {
+      HIP_TRY(hipEventSynchronize(L.ev_run[s]));
+      if (L.h_err[s]) {
+        drain();
+        return status_from_error_word(L.h_err[s]);
+      }
+    }
+    uint64_t end_bits = 0;
+    int64_t r;
+    uint8_t *dst = stream_out + bytes;
+    const size_t room = stream_cap - (size_t)bytes;
+    const int flags = (first ? 1 : 0) | (last ? 2 : 0);
+    if (brotli)
+      r = brotli_encode_jobs(L.eb, L.ev_enc[0], L.ev_enc[1], L.d_src, L.d_cjobs + k0, lens, L.d_out + L.cap_off[k0],
+                             L.d_out_off + s * (L.slice + 1), L.d_histos + k0,
+                             reinterpret_cast<const m4g_code *>(L.d_codes + L.cap_off[k0]), flags, dst, room, L.st_out,
+                             nullptr, "m4g_hostbatch_compress", pend_bits, &end_bits);
+    else
+      r = flate_encode_jobs(L.fb, L.ev_enc[0], L.ev_enc[1], L.d_src, L.d_cjobs + k0, lens, L.d_out + L.cap_off[k0],
+                            L.d_out_off + s * (L.slice + 1), flags | (format == M4G_FORMAT_GZIP ? 4 : 0), false, gzip_mtime,
+                            dst, room, L.st_out, nullptr, nullptr, "m4g_hostbatch_compress", pend_bits, &end_bits, &carry);
+    if (r < 0) {
+      drain();
+      if (r < -(int64_t)M4G_STREAM_NEEDED_BIAS) { // this slice did not fit: a bound for the whole stream
+        uint64_t total = 0;
+        for (size_t k = 0; k < n; k++) total += L.off[k + 1] - L.off[k];
+        return -(int64_t)(total + total / 4 + n * 1024 + 128 + M4G_STREAM_NEEDED_BIAS);
+      }
+      return r;
+    }
+    if (r > 0) dst[0] |= pend_byte;
+    const uint64_t whole = last ? (uint64_t)r : end_bits / 8;
+    pend_bits = last ? 0u : (unsigned)(end_bits & 7);
+    pend_byte = pend_bits ? dst[whole] : 0;
+    bytes += whole;
+  }
+  drain();
+  return (int64_t)bytes;
 }
 
 // ===========================================================================

@@ -40,7 +40,7 @@ EXPORTS = [
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
     "m4g_batch_status", "m4g_batch_run_device_noalloc",
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
-    "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
+    "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
 ]
 
 _LIB = None
@@ -103,6 +103,8 @@ def lib():
         L.m4g_hostbatch_run.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
         L.m4g_hostbatch_run.restype = ctypes.c_int64
         L.m4g_hostbatch_destroy.argtypes = [vp]
+        L.m4g_hostbatch_compress.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, vp, vp, sz, vp, sz]
+        L.m4g_hostbatch_compress.restype = ctypes.c_int64
         L.m4g_hostbatch_destroy.restype = None
         L.m4g_batch_encode.argtypes = [vp, vp, sz, vp, vp, vp, vp, ctypes.c_int, vp, sz, vp,
                                        ctypes.POINTER(ctypes.c_float)]
@@ -629,6 +631,23 @@ class HostBatch:
         if r < 0:
             raise M4GError(f"m4g_hostbatch_run: out_cap too small, need {-r}")
         return out[:int(out_off[n])], out_off, (histos[:n] if want_histos else None)
+
+
+    def compress(self, base, chunk_off: Sequence[int], format: int = 0, mtime: int = 0,
+                 out: "np.ndarray | None" = None):
+        """m4g_hostbatch_compress: the chunks as ONE brotli (format 0) / deflate (1) / gzip (2) stream, one
+        meta-block / deflate block per chunk (fresh M4 per chunk); Match lists stay on the device.  Returns the
+        stream bytes, or with `out` (a uint8 array, e.g. PinnedBuffer.array) its length."""
+        a = _as_u8(base)
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        n = off.size - 1
+        buf = out if out is not None else np.zeros(int(a.size + a.size // 4 + (n + 1) * 1024 + 256), dtype=np.uint8)
+        r = lib().m4g_hostbatch_compress(self._h, format, mtime, a.ctypes.data if a.size else None, off.ctypes.data, n,
+                                         buf.ctypes.data, buf.size)
+        _check(r, "m4g_hostbatch_compress")
+        if r < 0:
+            raise M4GError(f"m4g_hostbatch_compress: stream_cap too small, {-r - STREAM_NEEDED_BIAS} always suffices")
+        return int(r) if out is not None else buf[:r].tobytes()
 
 
 def find_matches_batch(base, chunk_off: Sequence[int], devices: Sequence[int] = (0,),

@@ -233,6 +233,23 @@ int64_t m4g_hostbatch_run(m4g_hostbatch *h, const uint8_t *base, const uint64_t 
                           m4g_histo *histos);
 void m4g_hostbatch_destroy(m4g_hostbatch *h);
 
+/* Chunks in host memory -> ONE compressed stream in host memory, on the
+ * persistent handle (made with one device): for every chunk c, in order,
+ * what matchfinder.Writer.writeBlock does (matchfinder.go:81-87) with
+ * MatchFinder = AutoReset{&M4{params}} and Encoder = &brotli.Encoder{}
+ * (M4G_FORMAT_BROTLI), flate.NewEncoder() (M4G_FORMAT_FLATE) or
+ * flate.NewGZIPEncoder() (M4G_FORMAT_GZIP; gzip_mtime for time.Now()), then
+ * Close() with nothing buffered: one meta-block / deflate block per chunk,
+ * byte-identical to m4g_batch_encode / m4g_batch_flate_encode over the same
+ * chunks.  The Match lists never leave the device, so the link carries the
+ * input one way and the compressed stream the other (the host-memory batch
+ * call is bound by the 12-byte Match records it brings back).  Returns the
+ * stream length, -(bound + M4G_STREAM_NEEDED_BIAS) when stream_cap is too small
+ * (bound: a capacity that always suffices), or an M4G_ERR_*. */
+int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t gzip_mtime,
+                               const uint8_t *base, const uint64_t *chunk_off, size_t nchunks,
+                               uint8_t *stream_out, size_t stream_cap);
+
 /* Replaces: brotli.Encoder.Encode(dst, chunk, matches, false) called for every
  * chunk of the batch in chunk order on ONE Encoder (encoder.go:17-161), i.e.
  * what matchfinder.Writer does after FindMatches (matchfinder.go:84) -- the

@@ -123,3 +123,36 @@ def test_writer_token_range_error_and_reset():
     w.Write(data)
     w.Close()
     assert zlib.decompress(dest2.getvalue(), -15) == data
+
+
+@pytest.mark.parametrize("fmt,kw", [(m4.FORMAT_BROTLI, PARAMS_G), (m4.FORMAT_FLATE, m4.flate_m4_params(5)),
+                                    (m4.FORMAT_GZIP, m4.flate_m4_params(6))], ids=["brotli-G", "flate5", "gzip6"])
+def test_hostbatch_compress_equals_the_restated_encoders(fmt, kw):
+    """m4g_hostbatch_compress: chunks in host memory -> one stream, sliced and overlapped on the device; the bytes
+    must be what the restated encoder writes for the same chunks (fresh M4 per chunk), however the batch is sliced."""
+    from oracle_lib import OracleEncoder, OracleFlateEncoder
+    sizes = [70000, 0, 1 << 17, 3, 100000, 65536, 1, 90000] * 40 + [50000]  # 321 chunks
+    n = sum(sizes)
+    host = np.frombuffer(synth.text(n, 21), dtype=np.uint8)
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    chunks = [host[int(off[c]):int(off[c + 1])].tobytes() for c in range(len(sizes))]
+    enc = OracleEncoder() if fmt == m4.FORMAT_BROTLI else OracleFlateEncoder(fmt == m4.FORMAT_GZIP, 77)
+    want = b""
+    for c in chunks:
+        want += enc.Encode(c, OracleM4(**kw).FindMatches(c), False)
+    want += enc.Encode(b"", np.zeros((0, 3), np.uint32), True)
+    import os
+    for slice_env in (None, "64"):  # default slices (one here) and 6 slices
+        if slice_env:
+            os.environ["M4G_PIPE_SLICE"] = slice_env
+        try:
+            hb = m4.HostBatch(len(sizes), 1 << 17, (0,), **kw)
+            got = hb.compress(host, off, fmt, mtime=77)
+            assert got == want, slice_env
+            got2 = hb.compress(host[:int(off[5])], off[:6], fmt, mtime=77)  # the handle again, fewer chunks
+            assert decode(fmt, got2, int(off[5])) == host[:int(off[5])].tobytes()
+            assert decode(fmt, hb.compress(b"", np.zeros(1, np.uint64), fmt, mtime=77), 0) == b""
+            hb.close()
+        finally:
+            os.environ.pop("M4G_PIPE_SLICE", None)
+    assert decode(fmt, want, n) == host.tobytes()
