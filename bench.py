@@ -579,6 +579,21 @@ def main():
         dt_hb = time.perf_counter() - t0
         same_as_device = bool((poff.astype(np.int64) == o[:ps + 1]).all()) and \
             bool((pm == got_all[:int(o[ps])]).all())
+        # the same chunks as ONE brotli stream (m4g_hostbatch_compress): the stream comes home, not the Match lists
+        compress = None
+        if args.params == "G" and not args.no_gpu_encode:
+            try:
+                hb.compress(pin_in.array, off[:ps + 1], m4.FORMAT_BROTLI, out=pin_out.array)  # warm: encoder buffers
+                t0 = time.perf_counter()
+                nb = hb.compress(pin_in.array, off[:ps + 1], m4.FORMAT_BROTLI, out=pin_out.array)
+                dt_c = time.perf_counter() - t0
+                compress = {"value": round(ps * n / dt_c / 1e9, 3), "ms": round(dt_c * 1e3, 1), "stream_bytes": nb,
+                            "compression_ratio": round(ps * n / nb, 4)}
+                if gpu_encode and "first" in gpu_encode:  # same bytes as the device-resident encoder's first MiB
+                    k = min(1 << 20, nb) - 8
+                    compress["equals_m4g_batch_encode_prefix"] = bytes(pin_out.array[:k]) == gpu_encode["first"][:k]
+            except m4.M4GError as e:
+                compress = {"error": str(e)}
         hb.close()
         out["end_to_end"] = {
             "value": round(sample * n / dt / 1e9, 3), "unit": "GB/s",
@@ -586,11 +601,14 @@ def main():
             "value_pinned_persistent": round(ps * n / dt_hb / 1e9, 3),
             "persistent_sample_chunks": ps,
             "persistent_equals_device_path": same_as_device,
+            "compress_brotli_pinned_persistent": compress,
             "sample": f"m4g_find_matches_batch on the first {sample} chunks: workspace allocation + H2D + kernels + "
                       f"D2H of matches and histograms; `value` from pageable numpy memory (fresh output array), "
                       f"`value_pinned` with input and output in m4g_host_alloc buffers; `value_pinned_persistent`: "
                       f"m4g_hostbatch_run on {ps} chunks from page-locked buffers, handle created beforehand "
-                      f"(H2D + kernels + D2H of matches and histograms, sliced and overlapped)",
+                      f"(H2D + kernels + D2H of matches and histograms, sliced and overlapped); "
+                      f"`compress_brotli_pinned_persistent`: m4g_hostbatch_compress on the same chunks and handle "
+                      f"(H2D + kernels + encoder + D2H of the brotli stream)",
         }
         pin_in.close()
         pin_out.close()
