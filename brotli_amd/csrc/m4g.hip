@@ -2084,6 +2084,9 @@ extern "C" int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t
     J.len = (uint32_t)len;
     L.h_cjobs[k] = J;
   }
+  auto drain = [&]() { // (copies from / to the caller's buffers must not outlive the call)
+    for (hipStream_t st : {L.st_in, L.st_run, L.st_out}) (void)hipStreamSynchronize(st);
+  };
   // enqueue: job list, then per slice its upload and its kernels
   if (n) HIP_TRY(hipMemcpyAsync(L.d_cjobs, L.h_cjobs, n * sizeof(Job), hipMemcpyHostToDevice, L.st_in));
   const size_t nsl = (n + L.slice - 1) / L.slice;
@@ -2097,14 +2100,14 @@ extern "C" int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t
         L.plan, L.d_src, L.off.data() + k0, nc, L.d_out + L.cap_off[k0], L.d_out_off + s * (L.slice + 1),
         L.cap_off[k1] - L.cap_off[k0], brotli ? L.d_histos + k0 : nullptr,
         brotli ? reinterpret_cast<m4g_code *>(L.d_codes + L.cap_off[k0]) : nullptr, L.st_run);
-    if (rc) return rc;
+    if (rc) {
+      drain();
+      return rc;
+    }
     HIP_TRY(hipMemcpyAsync(L.h_err + s, L.plan->W.d_errors, 4, hipMemcpyDeviceToHost, L.st_run));
     HIP_TRY(hipEventRecord(L.ev_run[s], L.st_run));
   }
   // encode slice after slice; the stream continues at bit granularity
-  auto drain = [&]() {
-    for (hipStream_t st : {L.st_in, L.st_run, L.st_out}) (void)hipStreamSynchronize(st);
-  };
   uint64_t bytes = 0; // whole bytes of the stream so far
   unsigned pend_bits = 0;
   uint8_t pend_byte = 0;
