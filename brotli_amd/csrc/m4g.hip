@@ -2684,6 +2684,7 @@ struct m4g_writer {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   std::vector<uint8_t> stage;
   bool closed_pending = false; // Close() has encoded the last block; its bytes wait for a large enough `out`
+  bool failed = false;         // a call failed half way: the handle's state is undefined until m4g_writer_reset
 };
 
 namespace {
@@ -2752,7 +2753,13 @@ int writer_encode(m4g_writer *w, const uint8_t *d_src, const Job *d_jobs, const 
 }
 
 // blocks of `bs` bytes of span (the last one may be shorter) -> outq.  final: the span is Close()'s remainder.
+int writer_process_impl(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bool final);
 int writer_process(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bool final) {
+  const int rc = writer_process_impl(w, span, len, bs, final);
+  if (rc) w->failed = true;
+  return rc;
+}
+int writer_process_impl(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bool final) {
   m4g_ctx *c = w->ctx;
   const Params &p = c->p;
   HIP_TRY(hipSetDevice(w->device));
@@ -2869,12 +2876,15 @@ extern "C" int m4g_writer_reset(m4g_writer *w) {
   w->pend_byte = 0;
   w->pend_bits = 0;
   w->carry = GzipCarry();
+  w->closed_pending = false;
+  w->failed = false;
   return m4g_reset(w->ctx);
 }
 
 extern "C" int64_t m4g_writer_write(m4g_writer *w, const uint8_t *src, size_t n, uint8_t *out, size_t out_cap) {
   if (!w || (!src && n) || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
   if (n >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "at most 2 GiB per Write");
+  if (w->failed) return fail(M4G_ERR_BAD_PARAM, "m4g_writer: an earlier call failed; m4g_writer_reset first");
   if (w->bs == 0) { // each Write is one block (matchfinder.go:64-66)
     if (int rc = writer_process(w, src, n, 0, false)) return rc;
     return writer_drain(w, out, out_cap);
@@ -2905,6 +2915,7 @@ extern "C" int64_t m4g_writer_write(m4g_writer *w, const uint8_t *src, size_t n,
 
 extern "C" int64_t m4g_writer_close(m4g_writer *w, uint8_t *out, size_t out_cap) {
   if (!w || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (w->failed) return fail(M4G_ERR_BAD_PARAM, "m4g_writer: an earlier call failed; m4g_writer_reset first");
   if (!w->closed_pending) {
     if (int rc = writer_process(w, w->inbuf.data(), w->inbuf.size(), w->bs, true)) return rc; // matchfinder.go:89-93
     w->inbuf.clear();
