@@ -84,6 +84,21 @@ def lib():
         L.flateref_free_buf.argtypes = [ctypes.c_void_p]
         L.flateref_crc32.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
         L.flateref_crc32.restype = ctypes.c_uint32
+        # oracle/bargain_ref.h
+        L.bargainref_new.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int]
+        L.bargainref_new.restype = ctypes.c_void_p
+        L.bargainref_free.argtypes = [ctypes.c_void_p]
+        L.bargainref_reset.argtypes = [ctypes.c_void_p]
+        L.bargainref_find_matches_flat.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                   ctypes.c_void_p, ctypes.c_size_t]
+        L.bargainref_find_matches_flat.restype = ctypes.c_int64
+        L.bargainref_find_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.bargainref_find_blocks.restype = ctypes.c_int64
+        L.bargainref_byte_cost_bits.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+        L.bargainref_byte_cost_bits.restype = ctypes.c_uint32
+        L.bargainref_log2.argtypes = [ctypes.c_double]
+        L.bargainref_log2.restype = ctypes.c_double
         _LIB = L
     return _LIB
 
@@ -152,6 +167,43 @@ class OracleM4:
         out = ctypes.string_at(p, osz.value)
         lib().encref_free_buf(p)
         return out, nm.value
+
+
+class OracleBargain:
+    """matchfinder.Bargain1 / Bargain2 / Bargain3 restated in C (oracle/bargain_ref.c)."""
+
+    def __init__(self, variant: int = 1, MaxDistance: int = 0, Skip: bool = False):
+        self.variant, self.MaxDistance, self.Skip = variant, MaxDistance, Skip
+        self._h = lib().bargainref_new(variant, MaxDistance, 1 if Skip else 0)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bargainref_free(self._h)
+            self._h = None
+
+    def Reset(self):
+        lib().bargainref_reset(self._h)
+
+    def FindMatches(self, src) -> np.ndarray:
+        addr, n, keep = _buf(src)
+        cap = n // 3 + 8
+        out = np.empty((cap, 3), dtype=np.uint32)
+        r = lib().bargainref_find_matches_flat(self._h, addr, n, out.ctypes.data, cap)
+        if r < 0:
+            raise RuntimeError("oracle: out_cap too small")
+        return out[:r].copy()
+
+    def find_blocks(self, data, block_size: int = 1 << 16):
+        """The Writer's loop (matchfinder.go:59-93): one FindMatches per block.  Returns (matches, block_off)."""
+        addr, n, keep = _buf(data)
+        nb = (n + block_size - 1) // block_size
+        cap = n // 3 + 8 + nb
+        out = np.empty((cap, 3), dtype=np.uint32)
+        off = np.zeros(nb + 1, dtype=np.uint64)
+        r = lib().bargainref_find_blocks(self._h, addr, n, block_size, out.ctypes.data, cap, off.ctypes.data)
+        if r < 0:
+            raise RuntimeError("oracle: out_cap too small")
+        return out[:r].copy(), off
 
 
 def flate_m4_params(level: int) -> dict:
