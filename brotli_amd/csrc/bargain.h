@@ -1,0 +1,489 @@
+// bargain.h -- matchfinder.Bargain1 / Bargain2 on the GPU.
+//
+// What the reference does (matchfinder/bargain1.go:38-208, bargain2.go): per
+// block handed to FindMatches, a shortest-path search over "arrivals" (cheapest
+// known way to reach each position, float32 bit costs), fed by one hash-table
+// candidate per table and a repeat-distance probe at every position, then a
+// backward walk that turns the path into Matches.
+//
+// How it is spread over the GPU:
+//   * the hash tables are inserted unconditionally and in position order
+//     (bargain1.go:141-146), so "the table entry before position i" is the chain
+//     entry K1 already computes (k1_xchg.h, XH form: this finder's multiplier);
+//     history slides (bargain1.go:66-80) only clear entries the distance test of
+//     :166 rejects anyway;
+//   * every block's search is independent of the other blocks' (fresh arrivals,
+//     bargain1.go:55-64): ONE WAVE per block walks the positions in order --
+//     the costs are sums of float32 roundings, there is no way to cut that chain
+//     -- and its 64 lanes do the parts that are parallel: candidate checks and
+//     forward / backward extension for 64 positions ahead of the walk, the
+//     arrival range a match updates (bargain1.go:97-107), the probe of one
+//     repeat distance at 64 positions, long extensions 512 bytes per step;
+//   * arrivals live in an LDS ring around the walk (KB_WIN entries); what falls
+//     out goes to a per-wave array in HBM, which the backward walk reads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace m4g {
+
+constexpr int KB_WIN = 512;  // arrivals in LDS per wave (ring; positions [wlo, wlo + KB_WIN))
+constexpr int KB_BACK = 128; // of which at least this many behind the current batch of 64
+constexpr int KB_FCAP = 32;  // bytes beyond the first 4 compared ahead of the walk
+constexpr int KB_MAX_TABLES = 2;
+
+struct BBlock {
+  uint32_t job;   // chunk (stream) the block belongs to
+  uint32_t start; // first position of the block in its chunk = len(history) at the call
+  uint32_t len;   // > 0
+  uint32_t pad;
+};
+
+struct KbTable {
+  uint32_t mul_lo, mul_hi; // hash = ((u & mask) * mul) >> (64 - bits)
+  uint32_t mask_lo, mask_hi;
+  uint32_t bits, pad;
+  uint64_t chain_base_off; // element offset of this table's chain array in the chain base
+};
+
+struct KbParams {
+  uint32_t max_distance, skip, overlap, block_size;
+  KbTable t[KB_MAX_TABLES];
+};
+
+// ---- Go's math.Log2 (pure Go on amd64: log.go, log10.go), operation for operation.
+// The literal costs are float32 roundings of it (bargain1.go:47-51).
+__device__ inline double kb_go_log(double x) {
+#pragma clang fp contract(off)
+  const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10,
+               L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+               L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+               L7 = 1.479819860511658591e-01;
+  int ki;
+  double f1 = frexp(x, &ki);
+  if (f1 < 0.70710678118654752440) {
+    f1 *= 2;
+    ki--;
+  }
+  const double f = f1 - 1;
+  const double k = (double)ki;
+  const double s = f / (2 + f);
+  const double s2 = s * s;
+  const double s4 = s2 * s2;
+  const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+  const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+  const double R = t1 + t2;
+  const double hfsq = 0.5 * f * f;
+  return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+__device__ inline float kb_byte_cost_of(uint32_t total, uint32_t count) {
+#pragma clang fp contract(off)
+  if (count == 0) return __builtin_inff(); // Log2(+Inf); a byte that does not occur is never priced
+  const double x = (double)total / (double)count; // >= 1
+  int e;
+  const double frac = frexp(x, &e);
+  double c;
+  if (frac == 0.5) c = (double)(e - 1);
+  else c = kb_go_log(frac) * (1 / 0.693147180559945309417232121458176568) + (double)e;
+  if (c < 1) c = 1;
+  return (float)c;
+}
+
+// byteCost of every block (bargain1.go:43-51): one workgroup per block.
+__global__ __launch_bounds__(256) void kb_byte_cost(const uint8_t *__restrict__ src_base, const Job *__restrict__ jobs,
+                                                    const BBlock *__restrict__ blocks, uint32_t nblocks,
+                                                    float *__restrict__ out) {
+  __shared__ uint32_t h[4][256]; // one histogram per wave
+  const uint32_t b = blockIdx.x;
+  if (b >= nblocks) return;
+  const BBlock B = blocks[b];
+  const uint8_t *src = src_base + jobs[B.job].src_off + B.start;
+  const uint32_t tid = threadIdx.x, w = tid >> 6;
+  for (int k = 0; k < 4; k++) h[k][tid] = 0;
+  __syncthreads();
+  // 16 bytes per thread and step once the address is 16-byte aligned
+  const uint32_t head = min(B.len, (uint32_t)((16 - ((uintptr_t)src & 15)) & 15));
+  if (tid < head) atomicAdd(&h[w][src[tid]], 1u);
+  const uint32_t nvec = (B.len - head) / 16;
+  const uint4 *v = reinterpret_cast<const uint4 *>(src + head);
+  for (uint32_t k = tid; k < nvec; k += 256) {
+    const uint4 q = v[k];
+    const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      atomicAdd(&h[w][ws[j] & 255], 1u);
+      atomicAdd(&h[w][(ws[j] >> 8) & 255], 1u);
+      atomicAdd(&h[w][(ws[j] >> 16) & 255], 1u);
+      atomicAdd(&h[w][ws[j] >> 24], 1u);
+    }
+  }
+  for (uint32_t k = head + nvec * 16 + tid; k < B.len; k += 256) atomicAdd(&h[w][src[k]], 1u);
+  __syncthreads();
+  const uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+  out[(size_t)b * 256 + tid] = kb_byte_cost_of(B.len, c);
+}
+
+__device__ inline uint64_t kb_ld64(const uint8_t *p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__device__ inline uint32_t kb_ld32(const uint8_t *p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+// 8 bytes at src + off where the buffer ends at lim (bytes past it read as 0)
+__device__ inline uint64_t kb_ld64s(const uint8_t *src, uint64_t off, uint64_t lim) {
+  if (off + 8 <= lim) return kb_ld64(src + off);
+  uint64_t v = 0;
+  for (int t = 0; t < 8; t++)
+    if (off + t < lim) v |= (uint64_t)src[off + t] << (8 * t);
+  return v;
+}
+__device__ inline uint32_t kb_bitlen(uint32_t x) { return x ? 32u - (uint32_t)__builtin_clz(x) : 0u; }
+
+// Number of equal bytes of src[a..] and src[b..] (a < b), at most KB_FCAP and at most maxf.
+__device__ inline uint32_t kb_fwd32(const uint8_t *src, uint64_t a, uint64_t b, uint32_t maxf, uint64_t lim) {
+  uint32_t f = 0;
+#pragma unroll
+  for (int q = 0; q < KB_FCAP / 8; q++) {
+    const uint64_t x = kb_ld64s(src, a + 8 * q, lim) ^ kb_ld64s(src, b + 8 * q, lim);
+    if (x) {
+      f += (uint32_t)__builtin_ctzll(x) >> 3;
+      break;
+    }
+    f += 8;
+  }
+  return min(f, maxf);
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void kb_parse(
+    const uint8_t *__restrict__ src_base, uint64_t src_total, const uint32_t *__restrict__ chain_base,
+    const Job *__restrict__ jobs, const BBlock *__restrict__ blocks, uint32_t nblocks,
+    const float *__restrict__ byte_cost, uint2 *__restrict__ ws_ld, float *__restrict__ ws_cost, uint32_t ws_stride,
+    m4g_match *__restrict__ stage, uint32_t stage_cap, uint32_t *__restrict__ counts, KbParams P) {
+  __shared__ uint32_t wl[KB_WIN], wd[KB_WIN];
+  __shared__ float wc[KB_WIN];
+  __shared__ float bc[256];
+  constexpr uint32_t M = KB_WIN - 1;
+  const uint32_t lane = threadIdx.x;
+  uint2 *gLD = ws_ld + (size_t)blockIdx.x * ws_stride;
+  float *gC = ws_cost + (size_t)blockIdx.x * ws_stride;
+
+#pragma unroll 1
+  for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const BBlock B = blocks[b];
+    const Job J = jobs[B.job];
+    const uint8_t *src = src_base + J.src_off;
+    const uint64_t lim = src_total - J.src_off;
+    const uint32_t hs = B.start, n = B.len, he = hs + n;
+    const uint32_t *chain[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) chain[t] = chain_base + P.t[t].chain_base_off + J.chain_off;
+
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) bc[lane + 64 * k] = byte_cost[(size_t)b * 256 + lane + 64 * k];
+#pragma unroll
+    for (int k = 0; k < KB_WIN / 64; k++) wl[lane + 64 * k] = 0, wd[lane + 64 * k] = 0, wc[lane + 64 * k] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // position 0 of the stream: the table slot of its hash holds {0, its bytes}, every other
+    // slot that nobody has written holds {0, 0} (zfast.go:8-11); K1 reports both as "no predecessor"
+    const bool pos0_inserted = min(P.block_size, J.len) >= 8;
+    const uint32_t src0 = J.len >= 4 ? kb_ld32(src) : 0u;
+    uint32_t h0[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      h0[t] = 0;
+      if (pos0_inserted) {
+        const uint64_t u = kb_ld64(src);
+        const uint64_t mul = (uint64_t)P.t[t].mul_hi << 32 | P.t[t].mul_lo, mask = (uint64_t)P.t[t].mask_hi << 32 | P.t[t].mask_lo;
+        h0[t] = (uint32_t)(((u & mask) * mul) >> (64 - P.t[t].bits));
+      }
+    }
+
+    uint32_t wlo = 0; // ring = arrivals [wlo, wlo + KB_WIN); arrival k = after k bytes of the block
+    uint32_t ghw = 0; // highest arrival index ever written beyond the ring
+    int32_t nos = 0;  // nextOverlapSearch (chunk position)
+    uint32_t rep_pd = 0, rep_f = 0;
+    unsigned long long rep_mask = 0, rep_long = 0;
+
+    auto in_ring = [&](uint32_t k) { return k >= wlo && k - wlo < (uint32_t)KB_WIN; };
+    auto read_c = [&](uint32_t k) -> float {
+      if (in_ring(k)) return wc[k & M];
+      return (k < wlo || k <= ghw) ? gC[k] : 0.f;
+    };
+    auto read_d = [&](uint32_t k) -> uint32_t {
+      if (in_ring(k)) return wd[k & M];
+      return (k < wlo || k <= ghw) ? gLD[k].y : 0u;
+    };
+    auto write_a = [&](uint32_t k, uint32_t len, uint32_t dist, float cost) {
+      if (in_ring(k)) {
+        wl[k & M] = len, wd[k & M] = dist, wc[k & M] = cost;
+      } else {
+        gLD[k] = make_uint2(len, dist);
+        gC[k] = cost;
+      }
+    };
+
+    // addMatch (bargain1.go:86-108); all arguments wave-uniform
+    auto add_match = [&](uint32_t start, uint32_t end, uint32_t match, uint32_t unmatched, bool repeat) {
+      const uint32_t ks = start - hs;
+      const float start_cost = ks > 0 ? read_c(ks) : 0.f;
+      float cost = start_cost + 4.0f; // baseMatchCost, pathfinder.go:64
+      cost = cost + (float)kb_bitlen(unmatched);
+      cost = cost + (repeat ? 0.f : (float)kb_bitlen(start - match));
+      const uint32_t dist = start - match;
+      const int32_t k_lo = (int32_t)ks + 3, k_top = (int32_t)(end - hs);
+      const uint32_t ghw_before = ghw;
+      (void)ghw_before;
+#pragma unroll 1
+      for (int32_t top = k_top; top >= k_lo; top -= 64) {
+        const int32_t k = top - (int32_t)lane;
+        const bool act = k >= k_lo;
+        const float c = act ? read_c((uint32_t)k) : 0.f;
+        const bool stop = act && c > 0.f && c <= cost;
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(stop);
+        const uint32_t first = sm ? (uint32_t)__builtin_ctzll(sm) : 64u;
+        if (act && lane < first) write_a((uint32_t)k, (uint32_t)k - ks, dist, cost);
+        if (sm) break;
+      }
+      if ((uint32_t)k_top >= wlo + KB_WIN) ghw = max(ghw, (uint32_t)k_top);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+
+    // first position >= b0 where src[a0 + t] != src[b0 + t], at most he (extendMatch, m4.go:287-324)
+    auto wave_extend = [&](uint64_t a0, uint64_t b0) -> uint32_t {
+#pragma unroll 1
+      for (;;) {
+        const uint64_t pb = b0 + 8ull * lane;
+        const uint32_t nb = pb < he ? (uint32_t)min((uint64_t)8, he - pb) : 0u;
+        uint64_t x = 0;
+        if (nb) x = kb_ld64s(src, a0 + 8ull * lane, lim) ^ kb_ld64s(src, pb, lim);
+        if (nb && nb < 8) x &= (1ull << (8 * nb)) - 1;
+        const bool term = nb < 8 || x != 0;
+        const uint32_t tp = nb == 0 ? he : (uint32_t)pb + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : nb);
+        const unsigned long long tm = __builtin_amdgcn_ballot_w64(term);
+        if (tm) return (uint32_t)__builtin_amdgcn_readlane((int)tp, (int)__builtin_ctzll(tm));
+        a0 += 512, b0 += 512;
+      }
+    };
+    // equal bytes below (i, cand), at most maxb (extendMatch2's downward loop, m4.go:330-333)
+    auto wave_back = [&](uint32_t i, uint32_t cand, uint32_t maxb) -> uint32_t {
+      uint32_t base = 0;
+#pragma unroll 1
+      for (;;) {
+        const uint32_t o = base + lane + 1;
+        const bool act = o <= maxb;
+        const bool ne = !act || src[i - o] != src[cand - o];
+        const unsigned long long nm = __builtin_amdgcn_ballot_w64(ne);
+        if (nm) return base + (uint32_t)__builtin_ctzll(nm);
+        base += 64;
+      }
+    };
+
+#pragma unroll 1
+    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+      // ---- slide the ring: [b0 - KB_BACK, b0 - KB_BACK + KB_WIN)
+      while (wlo + KB_BACK < b0) {
+        const uint32_t k = wlo + lane, slot = k & M;
+        gLD[k] = make_uint2(wl[slot], wd[slot]);
+        gC[k] = wc[slot];
+        const uint32_t k2 = k + KB_WIN;
+        uint2 v = make_uint2(0, 0);
+        float cst = 0.f;
+        if (k2 <= ghw) v = gLD[k2], cst = gC[k2];
+        wl[slot] = v.x, wd[slot] = v.y, wc[slot] = cst;
+        wlo += 64;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+
+      // ---- phase A: lane = position b0 + lane
+      const uint32_t r_l = b0 + lane, i_l = hs + r_l;
+      const bool inb = r_l < n;
+      const uint32_t byte_l = inb ? src[i_l] : 0u;
+      const bool valid = inb && i_l + 8 <= he; // bargain1.go:136
+      uint64_t cv = 0;
+      if (valid) cv = kb_ld64(src + i_l);
+      const uint32_t cv32 = (uint32_t)cv;
+      uint32_t cand[NT], cf[NT], cb[NT];
+      unsigned long long okm[NT], flm[NT], blm[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        bool ok = false, f_long = false, b_long = false;
+        uint32_t c = 0, f = 0, bl = 0;
+        if (valid) {
+          const uint32_t ce = chain[t][i_l];
+          const uint32_t d = ce & ~kChainMaybe;
+          if (d > 0) {
+            c = i_l - d;
+            ok = d < P.max_distance && (ce & kChainMaybe) && kb_ld32(src + c) == cv32; // bargain1.go:166-167
+          } else {
+            const uint64_t mul = (uint64_t)P.t[t].mul_hi << 32 | P.t[t].mul_lo,
+                           mask = (uint64_t)P.t[t].mask_hi << 32 | P.t[t].mask_lo;
+            const uint32_t h = (uint32_t)(((cv & mask) * mul) >> (64 - P.t[t].bits));
+            ok = i_l > 0 && i_l < P.max_distance && src0 == cv32 && (cv32 == 0 || (pos0_inserted && h == h0[t]));
+          }
+          if (ok) {
+            const uint32_t maxf = he - (i_l + 4);
+            f = kb_fwd32(src, (uint64_t)c + 4, (uint64_t)i_l + 4, maxf, lim);
+            f_long = f == (uint32_t)KB_FCAP && maxf > (uint32_t)KB_FCAP;
+            const uint32_t maxb = min(r_l, c); // start > historyLen, candidate > 0
+            if (maxb > 0) {
+              if (c >= 8) { // (then i_l >= 8 too)
+                const uint64_t x = kb_ld64(src + i_l - 8) ^ kb_ld64(src + c - 8);
+                const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;
+                bl = min(eq, maxb);
+                b_long = eq == 8 && maxb > 8;
+              } else {
+                b_long = true;
+              }
+            }
+          }
+        }
+        cand[t] = c, cf[t] = f, cb[t] = bl;
+        okm[t] = __builtin_amdgcn_ballot_w64(ok);
+        flm[t] = __builtin_amdgcn_ballot_w64(f_long);
+        blm[t] = __builtin_amdgcn_ballot_w64(b_long);
+      }
+      const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid);
+      rep_pd = 0; // the repeat-probe cache is per batch
+
+      // ---- phase B: the walk, wave-uniform
+      const uint32_t steps = min(64u, n - b0);
+#pragma unroll 1
+      for (uint32_t t = 0; t < steps; t++) {
+        const uint32_t r = b0 + t, i = hs + r;
+        const uint32_t a_len = wl[r & M], a_dist = wd[r & M];
+        const float a_cost = wc[r & M];
+        const float n_cost = wc[(r + 1) & M];
+        const uint32_t unmatched = a_dist == 0 ? a_len : 0u;
+        uint32_t pd = 0;
+        if (unmatched != 0 && r > unmatched) pd = read_d(r - unmatched);
+        const uint32_t byte = (uint32_t)__builtin_amdgcn_readlane((int)byte_l, (int)t);
+        const float c1 = a_cost + bc[byte];
+        if (n_cost == 0.f || c1 < n_cost) {
+          wl[(r + 1) & M] = unmatched + 1, wd[(r + 1) & M] = 0, wc[(r + 1) & M] = c1;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (!(vmask >> t & 1)) continue;
+
+        // repeat match (bargain1.go:148-157)
+        if (pd != 0 && pd != wd[(r + 4) & M]) {
+          if (pd != rep_pd) {
+            bool eq = false, lng = false;
+            uint32_t f = 0;
+            if (valid && i_l >= pd) {
+              const uint32_t a = i_l - pd;
+              eq = kb_ld32(src + a) == cv32;
+              if (eq) {
+                const uint32_t maxf = he - (i_l + 4);
+                f = kb_fwd32(src, (uint64_t)a + 4, (uint64_t)i_l + 4, maxf, lim);
+                lng = f == (uint32_t)KB_FCAP && maxf > (uint32_t)KB_FCAP;
+              }
+            }
+            rep_f = f;
+            rep_mask = __builtin_amdgcn_ballot_w64(eq);
+            rep_long = __builtin_amdgcn_ballot_w64(lng);
+            rep_pd = pd;
+          }
+          if (rep_mask >> t & 1) {
+            uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)rep_f, (int)t);
+            if (rep_long >> t & 1) end = wave_extend((uint64_t)(i - pd) + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
+            add_match(i, end, i - pd, unmatched, true);
+          }
+        }
+
+        if (P.skip && (i & 1)) continue; // bargain1.go:159 (no slide moves the origin inside a batch chunk)
+
+        const bool nbu = wd[(r + 1) & M] == 0;
+        if (unmatched > 0 || (int32_t)i >= nos || nbu) {
+#pragma unroll
+          for (int q = 0; q < NT; q++) {
+            if (!(okm[q] >> t & 1)) continue;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand[q], (int)t);
+            uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)cf[q], (int)t);
+            if (flm[q] >> t & 1) end = wave_extend((uint64_t)c + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
+            uint32_t delta = (uint32_t)__builtin_amdgcn_readlane((int)cb[q], (int)t);
+            if (blm[q] >> t & 1) delta = wave_back(i, c, min(r, c));
+            if (delta == 0) {
+              add_match(i, end, c, unmatched, false);
+            } else { // extended backwards: with and without the extra (bargain1.go:172-178)
+              add_match(i - delta, end, c - delta, unmatched > delta ? unmatched - delta : 0u, false);
+              add_match(i, end, c, unmatched, false);
+            }
+            nos = max(nos, max((int32_t)i + 1, (int32_t)end - (int32_t)P.overlap));
+          }
+        }
+      }
+    }
+
+    // ---- the ring goes to HBM, then the backward walk (bargain1.go:184-207)
+    for (uint32_t k = wlo + lane; k <= n && k < wlo + KB_WIN; k += 64) {
+      gLD[k] = make_uint2(wl[k & M], wd[k & M]);
+      gC[k] = wc[k & M];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    m4g_match *st = stage + (size_t)b * stage_cap;
+    uint32_t top = stage_cap; // records are written downwards: the list comes out in stream order
+    bool have = false;
+    uint32_t cu = 0, cl = 0, cd = 0; // the record being built (matches[len(matches)-1])
+    uint32_t k = n;
+#pragma unroll 1
+    while (k >= 1) {
+      // arrivals k, k-1, ..., k-63 in lanes 0..63
+      uint2 v = make_uint2(1, 0);
+      if (k >= lane + 1) v = gLD[k - lane];
+      uint32_t o = 0;
+#pragma unroll 1
+      while (o < 64 && o < k) {
+        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)v.x, (int)o);
+        const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)v.y, (int)o);
+        if (dist > 0) {
+          if (have && top > 0) { // (top > 0: stage_cap holds the longest list a block can have)
+            top--;
+            if (lane == 0) st[top].unmatched = cu, st[top].length = cl, st[top].distance = cd;
+          }
+          have = true, cu = 0, cl = len, cd = dist;
+        } else {
+          if (!have) have = true, cu = 0, cl = 0, cd = 0;
+          cu = len;
+        }
+        o += max(len, 1u); // (every arrival 1..n has been written with length >= 1)
+      }
+      k -= min(o, k);
+    }
+    if (have && top > 0) {
+      top--;
+      if (lane == 0) st[top].unmatched = cu, st[top].length = cl, st[top].distance = cd;
+    }
+    if (lane == 0) counts[b] = stage_cap - top;
+  }
+}
+
+// Staged records (at the end of every block's stage slots) -> one list in block order.
+__global__ __launch_bounds__(256) void kb_compact(const m4g_match *__restrict__ stage, uint32_t stage_cap,
+                                                  const uint32_t *__restrict__ counts,
+                                                  const uint64_t *__restrict__ block_off, uint32_t nblocks,
+                                                  m4g_match *__restrict__ out) {
+  const uint32_t b = blockIdx.x;
+  if (b >= nblocks) return;
+  const uint32_t c = counts[b];
+  const uint32_t *s = reinterpret_cast<const uint32_t *>(stage + (size_t)b * stage_cap + (stage_cap - c));
+  uint32_t *d = reinterpret_cast<uint32_t *>(out + block_off[b]);
+  for (uint32_t k = threadIdx.x; k < c * 3; k += 256) d[k] = s[k];
+}
+
+} // namespace m4g

@@ -1,0 +1,289 @@
+// bargain_host.h -- host side of the m4g_bargain_* entry points (included by
+// m4g.hip: same translation unit, same helpers).  Kernels: bargain.h.
+#pragma once
+
+namespace {
+
+constexpr int kKbWavesPerCu = 16;
+
+struct BargainDesc {
+  int nt = 0;
+  int hash_len[KB_MAX_TABLES] = {0, 0};
+  KbParams P{};
+};
+
+// bargain1.go:10-13, 210-212; bargain2.go:10-13, 242-248; writer.go:142-150
+int bargain_desc(const m4g_bargain_params *in, BargainDesc *d) {
+  if (!in) return fail(M4G_ERR_BAD_PARAM, "NULL params");
+  BargainDesc D;
+  D.P.max_distance = in->max_distance ? (uint32_t)in->max_distance : 1u << 16; // bargain1.go:39-41
+  D.P.skip = in->skip ? 1u : 0u;
+  D.P.block_size = in->block_size ? (uint32_t)in->block_size : 1u << 16; // writer.go:156
+  if (in->max_distance < 0 || in->block_size < 0) return fail(M4G_ERR_BAD_PARAM, "negative field");
+  if (D.P.block_size < (uint32_t)KX_SUB + 7 || D.P.block_size > (1u << 24))
+    return fail(M4G_ERR_BAD_PARAM, "block_size must be 3847 .. 16 MiB");
+  auto table = [](KbTable &t, uint64_t prime, int shift, int hash_len, int bits) {
+    const uint64_t mul = prime << shift, mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
+    t.mul_lo = (uint32_t)mul, t.mul_hi = (uint32_t)(mul >> 32);
+    t.mask_lo = (uint32_t)mask, t.mask_hi = (uint32_t)(mask >> 32);
+    t.bits = (uint32_t)bits;
+  };
+  if (in->variant == 1) {
+    D.nt = 1, D.P.overlap = 4;
+    D.hash_len[0] = 6;
+    table(D.P.t[0], 227718039650203ull, 16, 6, 18);
+  } else if (in->variant == 2) {
+    D.nt = 2, D.P.overlap = 6;
+    D.hash_len[0] = 5, D.hash_len[1] = 8;
+    table(D.P.t[0], 889523592379ull, 24, 5, 18);
+    table(D.P.t[1], 0xcf1bbcdcb7a56463ull, 0, 8, 18);
+  } else {
+    return fail(M4G_ERR_BAD_PARAM, "variant must be 1 (Bargain1) or 2 (Bargain2); Bargain3's 12-byte hash is not built");
+  }
+  *d = D;
+  return M4G_OK;
+}
+
+} // namespace
+
+struct m4g_bargain {
+  BargainDesc d;
+  int device = 0;
+  size_t max_chunks = 0, max_total = 0, max_chunk_bytes = 0, max_blocks = 0;
+  size_t chain_words = 0; // per table
+  uint32_t nwaves = 0, ws_stride = 0, stage_cap = 0;
+  Job *d_jobs = nullptr, *h_jobs = nullptr;
+  BBlock *d_blocks = nullptr, *h_blocks = nullptr;
+  uint32_t *d_chain = nullptr, *d_counts = nullptr;
+  float *d_bc = nullptr, *d_wc = nullptr;
+  uint2 *d_wld = nullptr;
+  m4g_match *d_stage = nullptr;
+  uint64_t *d_off = nullptr, *h_total = nullptr;
+  hipEvent_t ev[5] = {};
+  float ms[4] = {0, 0, 0, 0};
+  size_t last_blocks = 0;
+};
+
+extern "C" void m4g_bargain_destroy(m4g_bargain *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  (void)hipFree(g->d_jobs);
+  (void)hipFree(g->d_blocks);
+  (void)hipFree(g->d_chain);
+  (void)hipFree(g->d_counts);
+  (void)hipFree(g->d_bc);
+  (void)hipFree(g->d_wc);
+  (void)hipFree(g->d_wld);
+  (void)hipFree(g->d_stage);
+  (void)hipFree(g->d_off);
+  (void)hipHostFree(g->h_jobs);
+  (void)hipHostFree(g->h_blocks);
+  (void)hipHostFree(g->h_total);
+  for (auto &e : g->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete g;
+}
+
+extern "C" int m4g_bargain_create(const m4g_bargain_params *params, int device, size_t max_chunks, size_t max_total_bytes,
+                                  size_t max_chunk_bytes, m4g_bargain **out) {
+  if (!out) return fail(M4G_ERR_BAD_PARAM, "NULL out");
+  *out = nullptr;
+  BargainDesc d;
+  if (int rc = bargain_desc(params, &d)) return rc;
+  if (!max_chunks || !max_total_bytes || !max_chunk_bytes) return fail(M4G_ERR_BAD_PARAM, "zero capacity");
+  if (max_chunk_bytes >= (1ull << 31)) return fail(M4G_ERR_TOO_LARGE, "chunks of 2 GiB or more");
+  if (d.P.skip && (d.P.block_size & 1) && max_chunk_bytes > 2ull * d.P.max_distance)
+    // bargain1.go:159 tests the parity of the HISTORY position, which a slide of odd length flips
+    return fail(M4G_ERR_BAD_PARAM, "Skip with an odd block_size needs chunks of at most 2 * max_distance bytes");
+  if (int rc = check_device(device)) return rc;
+  HIP_TRY(hipSetDevice(device));
+  if (int rc = k1_prepare()) return rc;
+  if (k1_use_sort()) return fail(M4G_ERR_NO_DEVICE, "the Bargain path needs the exchange form of K1");
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1x_chain_build<false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)k1x_lds_bytes(kMaxPartBits)));
+  m4g_bargain *g = new (std::nothrow) m4g_bargain();
+  if (!g) return fail(M4G_ERR_NO_MEMORY, "host allocation failed");
+  g->d = d;
+  g->device = device;
+  g->max_chunks = max_chunks, g->max_total = max_total_bytes, g->max_chunk_bytes = max_chunk_bytes;
+  g->max_blocks = max_total_bytes / d.P.block_size + max_chunks;
+  g->chain_words = max_total_bytes + 16 * max_chunks;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    m4g_bargain_destroy(g);
+    return fail(M4G_ERR_HIP, "hipGetDeviceProperties failed");
+  }
+  g->nwaves = (uint32_t)std::min<size_t>(g->max_blocks, (size_t)prop.multiProcessorCount * kKbWavesPerCu);
+  g->ws_stride = (uint32_t)((std::min<size_t>(d.P.block_size, max_chunk_bytes) + 1 + 127) & ~(size_t)63);
+  g->stage_cap = d.P.block_size / 3 + 2;
+  bool ok = true;
+  auto dev = [&](auto **p, size_t bytes) { ok = ok && hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(bytes, 256)) == hipSuccess; };
+  dev(&g->d_jobs, max_chunks * sizeof(Job));
+  dev(&g->d_blocks, g->max_blocks * sizeof(BBlock));
+  dev(&g->d_chain, g->chain_words * 4 * (size_t)d.nt);
+  dev(&g->d_counts, g->max_blocks * 4);
+  dev(&g->d_bc, g->max_blocks * 256 * sizeof(float));
+  dev(&g->d_wc, (size_t)g->nwaves * g->ws_stride * sizeof(float));
+  dev(&g->d_wld, (size_t)g->nwaves * g->ws_stride * sizeof(uint2));
+  dev(&g->d_stage, g->max_blocks * (size_t)g->stage_cap * sizeof(m4g_match));
+  dev(&g->d_off, (g->max_blocks + 1) * 8);
+  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g->h_jobs), max_chunks * sizeof(Job)) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g->h_blocks), g->max_blocks * sizeof(BBlock)) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g->h_total), 64) == hipSuccess;
+  for (auto &e : g->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    m4g_bargain_destroy(g);
+    return fail(M4G_ERR_NO_MEMORY, "device allocation failed (m4g_bargain_create)");
+  }
+  *out = g;
+  return M4G_OK;
+}
+
+extern "C" size_t m4g_bargain_block_count(const m4g_bargain *g, const uint64_t *chunk_off, size_t nchunks) {
+  if (!g || !chunk_off) return 0;
+  size_t nb = 0;
+  for (size_t c = 0; c < nchunks; c++) {
+    const uint64_t n = chunk_off[c + 1] - chunk_off[c];
+    nb += (size_t)((n + g->d.P.block_size - 1) / g->d.P.block_size);
+  }
+  return nb;
+}
+
+extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, const uint64_t *chunk_off, size_t nchunks,
+                                          m4g_match *d_out, size_t out_cap, uint64_t *d_block_off, void *hip_stream) {
+  if (!g || !d_src || !chunk_off || (!d_out && out_cap) || !d_block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (nchunks > g->max_chunks) return fail(M4G_ERR_TOO_LARGE, "more chunks than the plan holds");
+  HIP_TRY(hipSetDevice(g->device));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (nchunks == 0) {
+    HIP_TRY(hipMemsetAsync(d_block_off, 0, 8, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    g->last_blocks = 0;
+    return 0;
+  }
+  const uint64_t total = chunk_off[nchunks] - chunk_off[0];
+  if (total > g->max_total) return fail(M4G_ERR_TOO_LARGE, "more bytes than the plan holds");
+  if (int rc = fill_batch_jobs(g->h_jobs, chunk_off, nchunks, g->max_chunk_bytes)) return rc;
+  const uint32_t bs = g->d.P.block_size;
+  size_t nb = 0;
+  uint32_t max_len = 0;
+  for (size_t c = 0; c < nchunks; c++) {
+    const uint32_t n = g->h_jobs[c].len;
+    max_len = std::max(max_len, n);
+    for (uint32_t p = 0; p < n; p += bs) {
+      BBlock B{};
+      B.job = (uint32_t)c, B.start = p, B.len = std::min(bs, n - p);
+      g->h_blocks[nb++] = B;
+    }
+  }
+  g->last_blocks = nb;
+  if (nb == 0) {
+    HIP_TRY(hipMemsetAsync(d_block_off, 0, 8, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  }
+  HIP_TRY(hipMemcpyAsync(g->d_jobs, g->h_jobs, nchunks * sizeof(Job), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(g->d_blocks, g->h_blocks, nb * sizeof(BBlock), hipMemcpyHostToDevice, st));
+  const uint64_t src_total = chunk_off[nchunks];
+  HIP_TRY(hipEventRecord(g->ev[0], st));
+  // K1 per table: chain entry = distance to the latest earlier position with the same hash
+  int posbits = 1;
+  while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
+  const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
+  if (cb < 1) return fail(M4G_ERR_TOO_LARGE, "buffer positions need all 32 bits");
+  const int njobs = (int)nchunks;
+  for (int t = 0; t < g->d.nt; t++) {
+    const KbTable &T = g->d.P.t[t];
+    const int pb = std::min((int)T.bits, kMaxPartBits), nparts = 1 << ((int)T.bits - pb);
+    g->d.P.t[t].chain_base_off = (uint64_t)t * g->chain_words;
+    hipLaunchKernelGGL((k1x_chain_build<false, true>), dim3((unsigned)(((njobs + 7) / 8) * 8 * nparts)), dim3(KX_THREADS),
+                       k1x_lds_bytes(pb), st, d_src, src_total, g->d_chain + (size_t)t * g->chain_words, g->d_jobs,
+                       (uint32_t *)nullptr, njobs, g->d.hash_len[t], (int)T.bits, pb, cb, 0, (const StreamInfo *)nullptr,
+                       (uint32_t *)nullptr, T.mul_lo, T.mul_hi, bs);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(g->ev[1], st));
+  hipLaunchKernelGGL(kb_byte_cost, dim3((unsigned)nb), dim3(256), 0, st, d_src, g->d_jobs, g->d_blocks, (uint32_t)nb, g->d_bc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(g->ev[2], st));
+  const unsigned grid = (unsigned)std::min<size_t>(nb, g->nwaves);
+  if (g->d.nt == 1)
+    hipLaunchKernelGGL(kb_parse<1>, dim3(grid), dim3(64), 0, st, d_src, src_total, g->d_chain, g->d_jobs, g->d_blocks,
+                       (uint32_t)nb, g->d_bc, g->d_wld, g->d_wc, g->ws_stride, g->d_stage, g->stage_cap, g->d_counts, g->d.P);
+  else
+    hipLaunchKernelGGL(kb_parse<2>, dim3(grid), dim3(64), 0, st, d_src, src_total, g->d_chain, g->d_jobs, g->d_blocks,
+                       (uint32_t)nb, g->d_bc, g->d_wld, g->d_wc, g->ws_stride, g->d_stage, g->stage_cap, g->d_counts, g->d.P);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(g->ev[3], st));
+  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, g->d_counts, g->d_off, (int)nb);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(g->h_total, g->d_off + nb, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t nm = *g->h_total;
+  HIP_TRY(hipMemcpyAsync(d_block_off, g->d_off, (nb + 1) * 8, hipMemcpyDeviceToDevice, st));
+  if (nm <= out_cap && nm > 0) {
+    hipLaunchKernelGGL(kb_compact, dim3((unsigned)nb), dim3(256), 0, st, g->d_stage, g->stage_cap, g->d_counts, g->d_off,
+                       (uint32_t)nb, d_out);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(g->ev[4], st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int k = 0; k < 4; k++) HIP_TRY(hipEventElapsedTime(&g->ms[k], g->ev[k], g->ev[k + 1]));
+  if (nm > out_cap) return -(int64_t)(nm + M4G_STREAM_NEEDED_BIAS);
+  return (int64_t)nm;
+}
+
+extern "C" int m4g_bargain_last_timings(const m4g_bargain *g, float *ms, int cap) {
+  if (!g || !ms) return 0;
+  const int n = std::min(cap, 4);
+  for (int k = 0; k < n; k++) ms[k] = g->ms[k];
+  return n;
+}
+
+// One stream in host memory, cut into blocks as matchfinder.Writer does (matchfinder.go:59-93):
+// the Match lists of its blocks, block_off[k] = index of block k's first Match.
+extern "C" int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int device, const uint8_t *src, size_t n,
+                                           m4g_match *out, size_t out_cap, uint64_t *block_off) {
+  if ((!src && n) || (!out && out_cap) || !block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  BargainDesc d;
+  if (int rc = bargain_desc(params, &d)) return rc;
+  if (n == 0) {
+    block_off[0] = 0;
+    return 0;
+  }
+  m4g_bargain *g = nullptr;
+  if (int rc = m4g_bargain_create(params, device, 1, n, n, &g)) return rc;
+  const size_t nb = (n + d.P.block_size - 1) / d.P.block_size;
+  const size_t cap = n / 3 + 2 * nb + 8; // a Match is at least 3 bytes long, plus one literal-only record per block
+  uint8_t *d_src = nullptr;
+  m4g_match *d_out = nullptr;
+  uint64_t *d_off = nullptr;
+  int64_t r = M4G_OK;
+  auto cleanup = [&]() {
+    (void)hipFree(d_src);
+    (void)hipFree(d_out);
+    (void)hipFree(d_off);
+    m4g_bargain_destroy(g);
+  };
+  if (hipMalloc(reinterpret_cast<void **>(&d_src), n + 64) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&d_out), cap * sizeof(m4g_match)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&d_off), (nb + 1) * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    return fail(M4G_ERR_NO_MEMORY, "device allocation failed (m4g_bargain_find_blocks)");
+  }
+  const uint64_t chunk_off[2] = {0, n};
+  if (hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) r = fail(M4G_ERR_HIP, "upload failed");
+  if (r == M4G_OK) r = m4g_bargain_run_device(g, d_src, chunk_off, 1, d_out, cap, d_off, nullptr);
+  if (r >= 0) {
+    if ((uint64_t)r > out_cap) {
+      r = -(int64_t)((uint64_t)r + M4G_STREAM_NEEDED_BIAS);
+    } else if (hipMemcpy(block_off, d_off, (nb + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+               (r > 0 && hipMemcpy(out, d_out, (size_t)r * sizeof(m4g_match), hipMemcpyDeviceToHost) != hipSuccess)) {
+      r = fail(M4G_ERR_HIP, "download failed");
+    }
+  }
+  cleanup();
+  return r;
+}

@@ -96,12 +96,18 @@ __global__ __launch_bounds__(256) void kx_order_selftest(uint32_t *__restrict__ 
   if (bad) atomicAdd(mismatches, bad);
 }
 
-template <bool STREAM>
+// XH (batches for the Bargain match finders, bargain.h): the hash multiplier is
+// an argument -- ((u << s) * prime) >> (64 - bits) of bargain1.go:210-212 is
+// ((u & mask) * (prime << s)) >> (64 - bits) -- and every job is a stream cut into
+// blocks of `batch_block` bytes (>= KX_SUB + 7) whose last 7 positions are not
+// inserted (bargain1.go:136-139), as in the STREAM form.
+template <bool STREAM, bool XH = false>
 __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
     int hash_len, int table_bits, int part_bits, int check_bits, int dbg,
-    const StreamInfo *__restrict__ si, uint32_t *__restrict__ table_out) {
+    const StreamInfo *__restrict__ si, uint32_t *__restrict__ table_out,
+    uint32_t xmul_lo, uint32_t xmul_hi, uint32_t batch_block) {
   extern __shared__ uint32_t lds[];
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
   // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces
   const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
   const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
-  const uint32_t mul_lo = (uint32_t)kHashMul64, mul_hi = (uint32_t)(kHashMul64 >> 32);
+  const uint32_t mul_lo = XH ? xmul_lo : (uint32_t)kHashMul64, mul_hi = XH ? xmul_hi : (uint32_t)(kHashMul64 >> 32);
   const uint32_t shift = 32 - table_bits;
   const uint32_t idx_mask = part_size - 1;
   const uint32_t cb = (uint32_t)check_bits; // <= K1_MAX_CHECK_BITS and positions << cb fit 32 bits
@@ -197,6 +203,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
       if (sb >= st_x0) blk_end = min(st_xend, st_x0 + ((sb - st_x0) / st_block + 1) * st_block);
       else blk_end = st_x0; // history of earlier calls is never re-inserted (segments start at x0)
     }
+    if (XH && batch_block) blk_end = min(J.len, (sb / batch_block + 1) * batch_block);
 
     uint32_t key[KX_PER], in0 = 0;
     unsigned long long bal[KX_PER];
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
           // the block the tile starts in; a tile can also hold the end of the call's LAST block when
           // that one is shorter than a tile (every other block is longer than a tile)
           const bool in = rel < lim && (h >> part_bits) == q &&
-                          !(STREAM && ((pos + 7 >= blk_end && pos < blk_end) || pos + 7 >= st_xend));
+                          !((STREAM || XH) && ((pos + 7 >= blk_end && pos < blk_end) || pos + 7 >= st_xend));
           // check bits of the first 4 bytes (never 0: that value marks table
           // entries whose bytes are not known); cb >= 1 (launch_k1)
           const uint32_t ck = max(1u, (v[j].x * 0x9E3779B1u) >> (32 - cb));

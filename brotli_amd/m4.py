@@ -25,6 +25,12 @@ M4G_OK = 0
 ERR_BASE = -1000000
 
 
+class BargainParams(ctypes.Structure):
+    """m4g_bargain_params: matchfinder.Bargain1 / Bargain2 and the Writer's BlockSize."""
+    _fields_ = [("variant", ctypes.c_int32), ("max_distance", ctypes.c_int32),
+                ("skip", ctypes.c_int32), ("block_size", ctypes.c_int32)]
+
+
 class Params(ctypes.Structure):
     _fields_ = [("max_distance", ctypes.c_int32), ("min_length", ctypes.c_int32),
                 ("hash_len", ctypes.c_int32), ("table_bits", ctypes.c_int32),
@@ -41,6 +47,8 @@ EXPORTS = [
     "m4g_batch_status", "m4g_batch_run_device_noalloc",
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
     "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
+    "m4g_bargain_create", "m4g_bargain_destroy", "m4g_bargain_block_count", "m4g_bargain_run_device",
+    "m4g_bargain_last_timings", "m4g_bargain_find_blocks",
 ]
 
 _LIB = None
@@ -126,6 +134,16 @@ def lib():
         L.m4g_writer_destroy.argtypes = [vp]
         L.m4g_writer_destroy.restype = None
         L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
+        L.m4g_bargain_create.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, sz, sz, sz, ctypes.POINTER(vp)]
+        L.m4g_bargain_destroy.argtypes = [vp]
+        L.m4g_bargain_destroy.restype = None
+        L.m4g_bargain_block_count.argtypes = [vp, vp, sz]
+        L.m4g_bargain_block_count.restype = sz
+        L.m4g_bargain_run_device.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
+        L.m4g_bargain_run_device.restype = ctypes.c_int64
+        L.m4g_bargain_last_timings.argtypes = [vp, vp, ctypes.c_int]
+        L.m4g_bargain_find_blocks.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, vp, sz, vp, sz, vp]
+        L.m4g_bargain_find_blocks.restype = ctypes.c_int64
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
         L.m4g_host_free.argtypes = [vp]
@@ -447,6 +465,69 @@ class BatchPlan:
 
 
 FORMAT_BROTLI, FORMAT_FLATE, FORMAT_GZIP = 0, 1, 2
+
+
+class BargainPlan:
+    """matchfinder.Bargain1 / Bargain2 over independent streams (chunks), every stream cut into
+    blocks of BlockSize bytes as matchfinder.Writer does (m4g_bargain_*).  Device resident."""
+
+    def __init__(self, max_chunks: int, max_total_bytes: int, max_chunk_bytes: int, variant: int = 1,
+                 MaxDistance: int = 1 << 20, Skip: bool = False, BlockSize: int = 1 << 16, device: int = 0):
+        self.params = BargainParams(variant, MaxDistance, 1 if Skip else 0, BlockSize)
+        h = ctypes.c_void_p()
+        _check(lib().m4g_bargain_create(ctypes.byref(self.params), device, max_chunks, max_total_bytes,
+                                        max_chunk_bytes, ctypes.byref(h)), "m4g_bargain_create")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().m4g_bargain_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    def block_count(self, chunk_off) -> int:
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        return int(lib().m4g_bargain_block_count(self._h, off.ctypes.data, off.size - 1))
+
+    def run(self, d_src, chunk_off, d_out, d_block_off, stream: int = 0) -> int:
+        """d_src: uint8 tensor; d_out: tensor of 12-byte records; d_block_off: int64 tensor with
+        block_count() + 1 elements.  Returns the number of Matches."""
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        out_cap = d_out.numel() * d_out.element_size() // 12
+        rc = lib().m4g_bargain_run_device(self._h, d_src.data_ptr(), off.ctypes.data, off.size - 1,
+                                          d_out.data_ptr(), out_cap, d_block_off.data_ptr(),
+                                          stream if stream else None)
+        _check(rc, "m4g_bargain_run_device")
+        if rc < 0:
+            raise M4GError(f"m4g_bargain_run_device: out_cap too small, {-rc - STREAM_NEEDED_BIAS} records needed")
+        return int(rc)
+
+    def last_timings(self) -> List[float]:
+        ms = (ctypes.c_float * 4)()
+        n = lib().m4g_bargain_last_timings(self._h, ms, 4)
+        return [float(ms[k]) for k in range(n)]
+
+
+def bargain_find_blocks(data, variant: int = 1, MaxDistance: int = 1 << 20, Skip: bool = False,
+                        BlockSize: int = 1 << 16, device: int = 0):
+    """The FindMatches calls of matchfinder.Writer{MatchFinder: &Bargain1{...} | &Bargain2{...}, BlockSize}
+    over `data` (one Write, then Close), on the GPU.  Returns (matches (M, 3) uint32, block_off)."""
+    a = _as_u8(data)
+    n = a.size
+    P = BargainParams(variant, MaxDistance, 1 if Skip else 0, BlockSize)
+    bs = BlockSize or (1 << 16)
+    nb = (n + bs - 1) // bs
+    cap = n // 3 + 2 * nb + 8
+    out = np.empty((cap, 3), dtype=np.uint32)
+    off = np.zeros(nb + 1, dtype=np.uint64)
+    rc = lib().m4g_bargain_find_blocks(ctypes.byref(P), device, a.ctypes.data if n else None, n,
+                                       out.ctypes.data, cap, off.ctypes.data)
+    _check(rc, "m4g_bargain_find_blocks")
+    if rc < 0:
+        raise M4GError("m4g_bargain_find_blocks: out_cap too small")
+    return out[:rc].copy(), off
 
 
 class GPUWriter:

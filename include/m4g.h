@@ -433,6 +433,54 @@ int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uin
                                  m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
                                  m4g_histo *d_histos, void *hip_stream);
 
+/* ---- matchfinder.Bargain1 / Bargain2 ------------------------
+ * The shortest-path match finders that brotli.NewWriterV2 plugs into
+ * matchfinder.Writer for levels 5-8 (writer.go:142-148; Bargain1:
+ * matchfinder/bargain1.go:15-31, FindMatches :38-208; Bargain2: bargain2.go).
+ * The Writer hands FindMatches one block of BlockSize bytes at a time
+ * (matchfinder.go:59-93); what connects the calls is the hash table and the
+ * history.  Here a CHUNK is one such stream (fresh state: Reset(),
+ * bargain1.go:33-36) and a launch does every block of every chunk: K1 builds
+ * the tables' predecessor links for all positions, then one wavefront per block
+ * runs that block's search (float32 costs in the reference's operation order).
+ * Output: the Match lists of all blocks in (chunk, block) order and
+ * block_off[k] = index of block k's first Match (nblocks + 1 entries; blocks of
+ * chunk c: ceil(len_c / block_size), m4g_bargain_block_count() sums them).
+ * Bargain3 (12-byte hash, bargain3.go) is not built: variant 3 is
+ * M4G_ERR_BAD_PARAM. */
+typedef struct m4g_bargain_params {
+  int32_t variant;      /* 1 = Bargain1, 2 = Bargain2 */
+  int32_t max_distance; /* MaxDistance; 0 = 1 << 16 (bargain1.go:39-41); NewWriterV2 uses 1 << 20 */
+  int32_t skip;         /* Skip (bargain1.go:20-22, 159) */
+  int32_t block_size;   /* Writer.BlockSize; 0 = 1 << 16 (writer.go:156); 3847 .. 1 << 24 */
+} m4g_bargain_params;
+typedef struct m4g_bargain m4g_bargain;
+
+/* Plan: device workspace for launches of up to max_chunks chunks, max_total_bytes
+ * bytes together, no chunk longer than max_chunk_bytes (< 2 GiB).  Workspace:
+ * 4 B per byte and table (links) + 4 B per byte (staged Matches) + 1 KiB per
+ * block + 12 B x block_size per resident wavefront (16 per CU). */
+int m4g_bargain_create(const m4g_bargain_params *params, int device, size_t max_chunks,
+                       size_t max_total_bytes, size_t max_chunk_bytes, m4g_bargain **out);
+void m4g_bargain_destroy(m4g_bargain *g);
+size_t m4g_bargain_block_count(const m4g_bargain *g, const uint64_t *chunk_off, size_t nchunks);
+/* d_src / d_out / d_block_off: device memory; chunk_off: host, nchunks + 1
+ * entries.  Returns the number of Matches, -(needed + M4G_STREAM_NEEDED_BIAS)
+ * when out_cap is too small (d_block_off is valid then, d_out is not), or an
+ * M4G_ERR_*.  A Match is at least 3 bytes long and a block adds at most one
+ * literal-only record: out_cap = total / 3 + 2 x nblocks always suffices.
+ * Synchronises the stream before it returns. */
+int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, const uint64_t *chunk_off,
+                               size_t nchunks, m4g_match *d_out, size_t out_cap,
+                               uint64_t *d_block_off, void *hip_stream);
+/* Stage durations of the last run in ms: links (K1), byte costs, search, compaction. */
+int m4g_bargain_last_timings(const m4g_bargain *g, float *ms, int cap);
+/* One stream from host memory = the FindMatches calls of a Writer with this
+ * match finder over `src` (one Write, then Close).  block_off: host,
+ * ceil(n / block_size) + 1 entries. */
+int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int device, const uint8_t *src,
+                                size_t n, m4g_match *out, size_t out_cap, uint64_t *block_off);
+
 /* Host staging helpers for callers without a HIP binding (bench.py uses
  * torch tensors instead; the Go shim uses these): page-locked host memory.
  * Buffers handed to m4g_find_matches_batch / _blocks should come from here

@@ -1,0 +1,108 @@
+"""GPU parity of m4g_bargain_* against the restated Bargain1 / Bargain2 (oracle/bargain_ref.c) -- SURVEY §8(f).3.
+Match for Match, block for block (the costs are float32: equality of the Match lists means every rounding agreed)."""
+import os
+
+import numpy as np
+import pytest
+
+from brotli_amd import m4
+from oracle_lib import OracleBargain, OracleEncoder, brotli_decompress
+from test_bargain_oracle import OPTICKS, text
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_blocks(data, variant, md, skip, bs):
+    return OracleBargain(variant, md, skip).find_blocks(data, bs)
+
+
+def same(data, variant=1, md=1 << 20, skip=False, bs=1 << 16):
+    got, goff = m4.bargain_find_blocks(data, variant, md, skip, bs)
+    want, woff = oracle_blocks(data, variant, md, skip, bs)
+    assert np.array_equal(goff, woff), (goff[:8], woff[:8])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("skip", [False, True])
+def test_opticks(variant, skip):
+    """brotli_test.go:886-932: the reference's own test input and settings (MaxDistance 1 << 20, 1 << 16 blocks)."""
+    data = open(OPTICKS, "rb").read()
+    same(data, variant, 1 << 20, skip)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_kinds(variant):
+    rng = np.random.default_rng(5)
+    same(text(300000, 3), variant, bs=4096)
+    same(text(200001, 4), variant, bs=5000)                                       # ragged last block
+    same(bytes(rng.integers(0, 256, size=150000, dtype=np.uint8)), variant)       # no matches
+    same(bytes(rng.integers(0, 4, size=150000, dtype=np.uint8)), variant, bs=8192)
+    same(bytes(200000), variant, bs=65536)                                        # zeros: the empty table entry matches
+    same(b"abcdefg" * 30000, variant, bs=65536)                                   # one long match per block
+    same(text(70000, 8) * 3, variant, bs=65536)                                   # long repeats across blocks
+    same(text(40000, 9) + bytes(30000) + text(40000, 9), variant, bs=16384)
+    same(text(100000, 10), variant, md=0, bs=4096)                                # default MaxDistance 1 << 16
+    same(text(100000, 11), variant, md=5000, bs=4096)
+
+
+def test_tiny_and_edges():
+    for n in (1, 7, 8, 9, 63, 64, 65, 4095, 4096, 4097):
+        same(text(n, n), 1, bs=4096)
+    got, off = m4.bargain_find_blocks(b"", 1)
+    assert got.shape == (0, 3) and off.tolist() == [0]
+    with pytest.raises(m4.M4GError):
+        m4.bargain_find_blocks(b"x" * 100, 3)       # Bargain3 is not built
+    with pytest.raises(m4.M4GError):
+        m4.bargain_find_blocks(b"x" * 100, 1, BlockSize=1000)
+
+
+def test_stream_position_zero_is_a_candidate():
+    """Position 0's table slot holds {0, its bytes} and untouched slots hold {0, 0} (zfast.go:8-11): a later
+    position with position 0's hash matches it; one with another hash matches offset 0 only if its bytes are zero."""
+    head = b"0123456789"
+    same(head + text(5000, 12) + head + text(3000, 13), 1, bs=4096)
+    same(bytes(8) + text(5000, 12) + bytes(12) + text(3000, 13), 1, bs=4096)
+    same(b"\0\0\0\0abcd" + text(5000, 12) + bytes(12) + text(3000, 13), 2, bs=4096)
+
+
+def test_batch_of_streams_device():
+    import torch
+    rng = np.random.default_rng(1)
+    chunks = [text(int(rng.integers(1, 200000)), 20 + k) for k in range(9)] + [b""] + [text(65536 * 2, 40)]
+    bs = 1 << 16
+    off = np.zeros(len(chunks) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(c) for c in chunks])
+    total = int(off[-1])
+    plan = m4.BargainPlan(len(chunks), total, 1 << 20, variant=1, BlockSize=bs)
+    nb = plan.block_count(off)
+    d_src = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
+    d_out = torch.empty((total // 3 + 2 * nb + 8) * 3, dtype=torch.int32, device="cuda")
+    d_off = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
+    for rep in range(2):  # the plan's workspace is reused
+        nm = plan.run(d_src, off, d_out, d_off)
+        got = d_out.cpu().numpy().view(np.uint32).reshape(-1, 3)[:nm]
+        goff = d_off.cpu().numpy().astype(np.uint64)
+        want, woff, base = [], [0], 0
+        for c in chunks:
+            m, o = OracleBargain(1, 1 << 20, False).find_blocks(c, bs)
+            want.append(m)
+            woff.extend((o[1:] + base).tolist())
+            base += len(m)
+        assert goff.tolist() == woff
+        assert np.array_equal(got, np.concatenate(want))
+    assert len(plan.last_timings()) == 4
+
+
+def test_reference_criterion_on_gpu_matches():
+    """Writer{Bargain1, &Encoder{}, 1 << 16} with the GPU's Match lists decodes to the input."""
+    data = open(OPTICKS, "rb").read()
+    ms, off = m4.bargain_find_blocks(data, 1, 1 << 20, False, 1 << 16)
+    enc = OracleEncoder()
+    out = bytearray()
+    for b in range(len(off) - 1):
+        blk = data[b << 16:(b + 1) << 16]
+        out += enc.Encode(blk, ms[int(off[b]):int(off[b + 1])], last_block=False)
+    out += enc.Encode(b"", np.zeros((0, 3), np.uint32), last_block=True)
+    assert brotli_decompress(bytes(out), len(data)) == data
