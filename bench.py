@@ -181,6 +181,57 @@ def flate_leg(host, n: int, chunks: int, dev, device_index: int, no_cpu: bool) -
     return res
 
 
+def bargain_leg(host, n: int, chunks: int, dev, device_index: int, no_cpu: bool) -> dict:
+    """matchfinder.Bargain1 (what brotli.NewWriterV2 levels 5-6 plug in, writer.go:142-143) over the
+    first `chunks` chunks of the workload, every chunk one stream cut into 64 KiB blocks as matchfinder.Writer does.
+    Reported beside `value`; the first chunks are compared Match for Match with the restated finder."""
+    import numpy as np
+    import torch
+    from brotli_amd import m4
+    bs = 1 << 16
+    try:
+        plan = m4.BargainPlan(chunks, n * chunks, n, variant=1, MaxDistance=1 << 20, BlockSize=bs, device=device_index)
+        off = np.arange(chunks + 1, dtype=np.uint64) * n
+        nb = plan.block_count(off)
+        d_src = torch.empty(n * chunks + 64, dtype=torch.uint8, device=dev)
+        d_src[:n * chunks].copy_(torch.from_numpy(host[:n * chunks]))
+        d_out = torch.empty((n * chunks // 3 + 2 * nb + 8) * 3, dtype=torch.int32, device=dev)
+        d_off = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        plan.run(d_src, off, d_out, d_off)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nm = plan.run(d_src, off, d_out, d_off)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = plan.last_timings()
+    except m4.M4GError as e:
+        return {"error": str(e)}
+    res = {
+        "finder": "Bargain1{MaxDistance: 1 << 20}", "block_size": bs, "chunks": chunks, "blocks": nb,
+        "value": round(chunks * n / dt / 1e9, 3), "unit": "GB/s", "ms": round(dt * 1e3, 2),
+        "stage_ms": {"k1_links": round(st[0], 3), "byte_costs": round(st[1], 3), "search": round(st[2], 3),
+                     "compact": round(st[3], 3)},
+        "matches": nm, "bytes_per_match": round(chunks * n / max(nm, 1), 2),
+        "sample": f"the first {chunks} chunks of the workload, each a fresh stream of {n // bs} blocks; one wavefront "
+                  f"per block runs the shortest-path search (m4g_bargain_run_device, inputs and outputs in HBM)",
+    }
+    if not no_cpu:
+        from oracle_lib import OracleBargain
+        k = min(chunks, 4)
+        got = d_out.cpu().numpy().view(np.uint32).reshape(-1, 3)
+        base, ok = 0, True
+        t0 = time.perf_counter()
+        for c in range(k):
+            want, _ = OracleBargain(1, 1 << 20, False).find_blocks(host[c * n:(c + 1) * n], bs)
+            ok = ok and bool(np.array_equal(got[base:base + len(want)], want))
+            base += len(want)
+        dt = time.perf_counter() - t0
+        res["cpu_restated_MB_s_one_core"] = round(k * n / dt / 1e6, 1)
+        res["first_chunks_equal_restated_finder"] = ok
+        res["chunks_compared"] = k
+    return res
+
+
 def writer_leg(host, nbytes: int, device_index: int) -> dict:
     """matchfinder.Writer{M4, Encoder, BlockSize 1 << 16} over the first nbytes of the workload as ONE stream, host
     memory in, host memory out (m4g_writer: match finding with the history carried from block to block AND the
@@ -252,6 +303,8 @@ def parse_args():
                     help="skip the m4g_batch_encode leg (Encoder pass 2 on the GPU, SURVEY 8f.2)")
     ap.add_argument("--flate-chunks", type=int, default=256,
                     help="chunks of the flate leg (M4 at flate level 6 + m4g_batch_flate_encode, SURVEY 8f.4); 0 = skip")
+    ap.add_argument("--bargain-chunks", type=int, default=512,
+                    help="chunks of the Bargain1 leg (SURVEY 8f.3: the shortest-path match finder of NewWriterV2 5-6); 0 = skip")
     ap.add_argument("--writer-mib", type=int, default=256,
                     help="MiB of the workload compressed as ONE stream by m4g_writer (matchfinder.Writer on the GPU); 0 = skip")
     ap.add_argument("--e2e-sample-chunks", type=int, default=512)
@@ -616,6 +669,8 @@ def main():
         out["gpu_flate"] = flate_leg(host, n, min(C, args.flate_chunks), dev, local_rank, args.no_cpu_baseline)
     if rank == 0 and world == 1 and args.writer_mib > 0 and args.kind == "text" and not args.no_gpu_encode:
         out["gpu_writer"] = writer_leg(host, min(n * C, args.writer_mib << 20), local_rank)
+    if rank == 0 and world == 1 and args.bargain_chunks > 0 and args.kind == "text" and not args.no_gpu_encode:
+        out["gpu_bargain"] = bargain_leg(host, n, min(C, args.bargain_chunks), dev, local_rank, args.no_cpu_baseline)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

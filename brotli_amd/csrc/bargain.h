@@ -29,8 +29,8 @@
 
 namespace m4g {
 
-constexpr int KB_WIN = 512;  // arrivals in LDS per wave (ring; positions [wlo, wlo + KB_WIN))
-constexpr int KB_BACK = 128; // of which at least this many behind the current batch of 64
+constexpr int KB_WIN = 256;  // arrivals in LDS per wave (ring; positions [wlo, wlo + KB_WIN))
+constexpr int KB_BACK = 64;  // of which this many behind the current batch of 64 (the batch and the next 64 are in registers)
 constexpr int KB_FCAP = 32;  // bytes beyond the first 4 compared ahead of the walk
 constexpr int KB_MAX_TABLES = 2;
 
@@ -161,6 +161,61 @@ __device__ inline uint32_t kb_fwd32(const uint8_t *src, uint64_t a, uint64_t b, 
   return min(f, maxf);
 }
 
+// Everything the walk needs to know about the candidate c of position i (c < i, i + 8 <= he), from
+// loads that are all issued together (one memory round trip): are the first 4 bytes equal
+// (bargain1.go:167), how many of the next KB_FCAP bytes are (at most maxf), and how many of the 8 bytes
+// below (at most maxb; extendMatch2, m4.go:326-339).  cv = the 8 bytes at i.
+struct KbEval {
+  bool eq4, f_long, b_long;
+  uint32_t f, bl;
+};
+__device__ inline KbEval kb_eval(const uint8_t *src, uint64_t lim, uint32_t c, uint32_t i, uint64_t cv, uint32_t maxf,
+                                 uint32_t maxb) {
+  KbEval e;
+  e.bl = 0, e.b_long = false;
+  if ((uint64_t)i + 40 <= lim) {
+    uint64_t a[5], o[5], pa = 0, pi = 0;
+    const bool back = maxb > 0 && c >= 8;
+#pragma unroll
+    for (int q = 0; q < 5; q++) a[q] = kb_ld64(src + c + 8 * q);
+#pragma unroll
+    for (int q = 1; q < 5; q++) o[q] = kb_ld64(src + i + 8 * q);
+    if (back) pa = kb_ld64(src + c - 8), pi = kb_ld64(src + i - 8);
+    o[0] = cv;
+    e.eq4 = (uint32_t)a[0] == (uint32_t)cv;
+    const uint32_t x0 = (uint32_t)((a[0] ^ cv) >> 32), x4 = (uint32_t)(a[4] ^ o[4]);
+    const uint64_t x1 = a[1] ^ o[1], x2 = a[2] ^ o[2], x3 = a[3] ^ o[3];
+    uint32_t f;
+    if (x0) f = (uint32_t)__builtin_ctz(x0) >> 3;
+    else if (x1) f = 4 + ((uint32_t)__builtin_ctzll(x1) >> 3);
+    else if (x2) f = 12 + ((uint32_t)__builtin_ctzll(x2) >> 3);
+    else if (x3) f = 20 + ((uint32_t)__builtin_ctzll(x3) >> 3);
+    else f = x4 ? 28 + ((uint32_t)__builtin_ctz(x4) >> 3) : 32u;
+    e.f = min(f, maxf);
+    if (back) {
+      const uint64_t x = pa ^ pi;
+      const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;
+      e.bl = min(eq, maxb);
+      e.b_long = eq == 8 && maxb > 8;
+    } else if (maxb > 0) {
+      e.b_long = true; // the first 8 bytes of the stream: the walk compares byte by byte
+    }
+  } else { // the last bytes of the source buffer
+    e.eq4 = kb_ld32(src + c) == (uint32_t)cv;
+    e.f = kb_fwd32(src, (uint64_t)c + 4, (uint64_t)i + 4, maxf, lim);
+    e.b_long = maxb > 0;
+  }
+  e.f_long = e.f == (uint32_t)KB_FCAP && maxf > (uint32_t)KB_FCAP;
+  return e;
+}
+
+#ifdef KB_STATS
+__device__ unsigned long long kb_stats[8]; // rep evals, add_match calls, far calls, wave_extend, wave_back, pd lookups out of window
+#define KB_COUNT(k) (st_##k++)
+#else
+#define KB_COUNT(k) ((void)0)
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(64) void kb_parse(
     const uint8_t *__restrict__ src_base, uint64_t src_total, const uint32_t *__restrict__ chain_base,
@@ -209,13 +264,22 @@ __global__ __launch_bounds__(64) void kb_parse(
       }
     }
 
+#ifdef KB_STATS
+    uint32_t st_rep = 0, st_add = 0, st_far = 0, st_ext = 0, st_back = 0, st_pdfar = 0, st_cand = 0, st_repm = 0;
+#endif
     uint32_t wlo = 0; // ring = arrivals [wlo, wlo + KB_WIN); arrival k = after k bytes of the block
     uint32_t ghw = 0; // highest arrival index ever written beyond the ring
     int32_t nos = 0;  // nextOverlapSearch (chunk position)
     uint32_t rep_pd = 0, rep_f = 0;
     unsigned long long rep_mask = 0, rep_long = 0;
+    // Arrivals [b0, b0 + 128) of the batch being walked live in registers (lane l: b0 + l and
+    // b0 + 64 + l); their ring slots are stale until the batch ends.
+    uint32_t b0 = 0;
+    uint32_t L0 = 0, L1 = 0, D0 = 0, D1 = 0;
+    float C0 = 0.f, C1 = 0.f;
 
     auto in_ring = [&](uint32_t k) { return k >= wlo && k - wlo < (uint32_t)KB_WIN; };
+    // (the three below: never for k in [b0, b0 + 128))
     auto read_c = [&](uint32_t k) -> float {
       if (in_ring(k)) return wc[k & M];
       return (k < wlo || k <= ghw) ? gC[k] : 0.f;
@@ -232,39 +296,84 @@ __global__ __launch_bounds__(64) void kb_parse(
         gC[k] = cost;
       }
     };
+    // wave-uniform reads of the register window: idx = k - b0 < 128
+    auto rget = [&](uint32_t v0, uint32_t v1, uint32_t idx) -> uint32_t { // (both rows read: no branch)
+      const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)v0, (int)(idx & 63));
+      const uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane((int)v1, (int)(idx & 63));
+      return idx < 64 ? x0 : x1;
+    };
+    auto uread_d = [&](uint32_t k) -> uint32_t { // k wave-uniform
+      if (k - b0 < 128u) return rget(D0, D1, k - b0);
+      KB_COUNT(pdfar);
+      return (uint32_t)__builtin_amdgcn_readfirstlane((int)read_d(k));
+    };
+    auto uread_c = [&](uint32_t k) -> float {
+      if (k - b0 < 128u) return __uint_as_float(rget(__float_as_uint(C0), __float_as_uint(C1), k - b0));
+      return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(read_c(k))));
+    };
 
-    // addMatch (bargain1.go:86-108); all arguments wave-uniform
+    // addMatch (bargain1.go:86-108); all arguments wave-uniform.  The loop runs from m.End down and
+    // stops at the first arrival that is at least as cheap: per 64 arrivals, one ballot finds it.
     auto add_match = [&](uint32_t start, uint32_t end, uint32_t match, uint32_t unmatched, bool repeat) {
+      KB_COUNT(add);
       const uint32_t ks = start - hs;
-      const float start_cost = ks > 0 ? read_c(ks) : 0.f;
+      const float start_cost = ks > 0 ? uread_c(ks) : 0.f;
       float cost = start_cost + 4.0f; // baseMatchCost, pathfinder.go:64
       cost = cost + (float)kb_bitlen(unmatched);
       cost = cost + (repeat ? 0.f : (float)kb_bitlen(start - match));
       const uint32_t dist = start - match;
       const int32_t k_lo = (int32_t)ks + 3, k_top = (int32_t)(end - hs);
-      const uint32_t ghw_before = ghw;
-      (void)ghw_before;
+      const int32_t r_lo = (int32_t)b0, r_hi = (int32_t)b0 + 127;
+      bool stopped = false;
+      // arrivals [lo, top] outside the register window, 64 per step
+      auto far = [&](int32_t top_k, int32_t lo_k) {
+        KB_COUNT(far);
 #pragma unroll 1
-      for (int32_t top = k_top; top >= k_lo; top -= 64) {
-        const int32_t k = top - (int32_t)lane;
-        const bool act = k >= k_lo;
-        const float c = act ? read_c((uint32_t)k) : 0.f;
-        const bool stop = act && c > 0.f && c <= cost;
-        const unsigned long long sm = __builtin_amdgcn_ballot_w64(stop);
-        const uint32_t first = sm ? (uint32_t)__builtin_ctzll(sm) : 64u;
-        if (act && lane < first) write_a((uint32_t)k, (uint32_t)k - ks, dist, cost);
-        if (sm) break;
+        for (int32_t top = top_k; top >= lo_k; top -= 64) {
+          const int32_t k = top - (int32_t)lane;
+          const bool act = k >= lo_k;
+          const float c = act ? read_c((uint32_t)k) : 0.f;
+          const bool stop = act && c > 0.f && c <= cost;
+          const unsigned long long sm = __builtin_amdgcn_ballot_w64(stop);
+          const uint32_t first = sm ? (uint32_t)__builtin_ctzll(sm) : 64u;
+          if (act && lane < first) write_a((uint32_t)k, (uint32_t)k - ks, dist, cost);
+          if (sm) {
+            stopped = true;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      };
+      if (k_top > r_hi) {
+        far(k_top, max(k_lo, r_hi + 1));
+        if ((uint32_t)k_top >= wlo + KB_WIN) ghw = max(ghw, (uint32_t)k_top);
       }
-      if ((uint32_t)k_top >= wlo + KB_WIN) ghw = max(ghw, (uint32_t)k_top);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      if (!stopped && k_top >= r_lo + 64 && k_lo <= r_hi) {
+        const int32_t k = r_lo + 64 + (int32_t)lane;
+        const bool in = k >= k_lo && k <= k_top;
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(in && C1 > 0.f && C1 <= cost);
+        const int32_t hi = sm ? 63 - (int32_t)__builtin_clzll(sm) : -1;
+        if (in && (int32_t)lane > hi) L1 = (uint32_t)k - ks, D1 = dist, C1 = cost;
+        stopped = sm != 0;
+      }
+      if (!stopped && k_top >= r_lo && k_lo <= r_lo + 63) {
+        const int32_t k = r_lo + (int32_t)lane;
+        const bool in = k >= k_lo && k <= k_top;
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(in && C0 > 0.f && C0 <= cost);
+        const int32_t hi = sm ? 63 - (int32_t)__builtin_clzll(sm) : -1;
+        if (in && (int32_t)lane > hi) L0 = (uint32_t)k - ks, D0 = dist, C0 = cost;
+        stopped = sm != 0;
+      }
+      if (!stopped && k_lo < r_lo) far(min(k_top, r_lo - 1), k_lo);
     };
 
     // first position >= b0 where src[a0 + t] != src[b0 + t], at most he (extendMatch, m4.go:287-324)
-    auto wave_extend = [&](uint64_t a0, uint64_t b0) -> uint32_t {
+    auto wave_extend = [&](uint64_t a0, uint64_t p0) -> uint32_t {
+      KB_COUNT(ext);
 #pragma unroll 1
       for (;;) {
-        const uint64_t pb = b0 + 8ull * lane;
+        const uint64_t pb = p0 + 8ull * lane;
         const uint32_t nb = pb < he ? (uint32_t)min((uint64_t)8, he - pb) : 0u;
         uint64_t x = 0;
         if (nb) x = kb_ld64s(src, a0 + 8ull * lane, lim) ^ kb_ld64s(src, pb, lim);
@@ -273,11 +382,12 @@ __global__ __launch_bounds__(64) void kb_parse(
         const uint32_t tp = nb == 0 ? he : (uint32_t)pb + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : nb);
         const unsigned long long tm = __builtin_amdgcn_ballot_w64(term);
         if (tm) return (uint32_t)__builtin_amdgcn_readlane((int)tp, (int)__builtin_ctzll(tm));
-        a0 += 512, b0 += 512;
+        a0 += 512, p0 += 512;
       }
     };
     // equal bytes below (i, cand), at most maxb (extendMatch2's downward loop, m4.go:330-333)
     auto wave_back = [&](uint32_t i, uint32_t cand, uint32_t maxb) -> uint32_t {
+      KB_COUNT(back);
       uint32_t base = 0;
 #pragma unroll 1
       for (;;) {
@@ -291,7 +401,7 @@ __global__ __launch_bounds__(64) void kb_parse(
     };
 
 #pragma unroll 1
-    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+    for (b0 = 0; b0 < n; b0 += 64) {
       // ---- slide the ring: [b0 - KB_BACK, b0 - KB_BACK + KB_WIN)
       while (wlo + KB_BACK < b0) {
         const uint32_t k = wlo + lane, slot = k & M;
@@ -310,8 +420,8 @@ __global__ __launch_bounds__(64) void kb_parse(
       // ---- phase A: lane = position b0 + lane
       const uint32_t r_l = b0 + lane, i_l = hs + r_l;
       const bool inb = r_l < n;
-      const uint32_t byte_l = inb ? src[i_l] : 0u;
-      const bool valid = inb && i_l + 8 <= he; // bargain1.go:136
+      const float lit_l = inb ? bc[src[i_l]] : 0.f; // byteCost[src[i]], bargain1.go:127
+      const bool valid = inb && i_l + 8 <= he;        // bargain1.go:136
       uint64_t cv = 0;
       if (valid) cv = kb_ld64(src + i_l);
       const uint32_t cv32 = (uint32_t)cv;
@@ -324,30 +434,20 @@ __global__ __launch_bounds__(64) void kb_parse(
         if (valid) {
           const uint32_t ce = chain[t][i_l];
           const uint32_t d = ce & ~kChainMaybe;
+          bool pre;
           if (d > 0) {
             c = i_l - d;
-            ok = d < P.max_distance && (ce & kChainMaybe) && kb_ld32(src + c) == cv32; // bargain1.go:166-167
-          } else {
+            pre = d < P.max_distance && (ce & kChainMaybe); // bargain1.go:166
+          } else { // no predecessor: table entry {0, 0}, or {0, bytes of position 0} in position 0's slot
             const uint64_t mul = (uint64_t)P.t[t].mul_hi << 32 | P.t[t].mul_lo,
                            mask = (uint64_t)P.t[t].mask_hi << 32 | P.t[t].mask_lo;
             const uint32_t h = (uint32_t)(((cv & mask) * mul) >> (64 - P.t[t].bits));
-            ok = i_l > 0 && i_l < P.max_distance && src0 == cv32 && (cv32 == 0 || (pos0_inserted && h == h0[t]));
+            pre = i_l > 0 && i_l < P.max_distance && (cv32 == 0 || (pos0_inserted && h == h0[t]));
           }
-          if (ok) {
-            const uint32_t maxf = he - (i_l + 4);
-            f = kb_fwd32(src, (uint64_t)c + 4, (uint64_t)i_l + 4, maxf, lim);
-            f_long = f == (uint32_t)KB_FCAP && maxf > (uint32_t)KB_FCAP;
-            const uint32_t maxb = min(r_l, c); // start > historyLen, candidate > 0
-            if (maxb > 0) {
-              if (c >= 8) { // (then i_l >= 8 too)
-                const uint64_t x = kb_ld64(src + i_l - 8) ^ kb_ld64(src + c - 8);
-                const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;
-                bl = min(eq, maxb);
-                b_long = eq == 8 && maxb > 8;
-              } else {
-                b_long = true;
-              }
-            }
+          if (pre) {
+            const KbEval e = kb_eval(src, lim, c, i_l, cv, he - (i_l + 4), min(r_l, c));
+            ok = e.eq4; // bargain1.go:167
+            f = e.f, f_long = e.f_long, bl = e.bl, b_long = e.b_long;
           }
         }
         cand[t] = c, cf[t] = f, cb[t] = bl;
@@ -363,34 +463,33 @@ __global__ __launch_bounds__(64) void kb_parse(
 #pragma unroll 1
       for (uint32_t t = 0; t < steps; t++) {
         const uint32_t r = b0 + t, i = hs + r;
-        const uint32_t a_len = wl[r & M], a_dist = wd[r & M];
-        const float a_cost = wc[r & M];
-        const float n_cost = wc[(r + 1) & M];
+        const uint32_t a_len = (uint32_t)__builtin_amdgcn_readlane((int)L0, (int)t);
+        const uint32_t a_dist = (uint32_t)__builtin_amdgcn_readlane((int)D0, (int)t);
+        const float a_cost = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(C0), (int)t));
+        const float n_cost = __uint_as_float(rget(__float_as_uint(C0), __float_as_uint(C1), t + 1));
         const uint32_t unmatched = a_dist == 0 ? a_len : 0u;
         uint32_t pd = 0;
-        if (unmatched != 0 && r > unmatched) pd = read_d(r - unmatched);
-        const uint32_t byte = (uint32_t)__builtin_amdgcn_readlane((int)byte_l, (int)t);
-        const float c1 = a_cost + bc[byte];
-        if (n_cost == 0.f || c1 < n_cost) {
-          wl[(r + 1) & M] = unmatched + 1, wd[(r + 1) & M] = 0, wc[(r + 1) & M] = c1;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
+        if (unmatched != 0 && r > unmatched) pd = uread_d(r - unmatched);
+        const float c1 = a_cost + __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lit_l), (int)t));
+        bool nbu;
+        {
+          const bool relax = n_cost == 0.f || c1 < n_cost;
+          const bool w0 = relax && lane == t + 1, w1 = relax && t == 63 && lane == 0;
+          L0 = w0 ? unmatched + 1 : L0, D0 = w0 ? 0u : D0, C0 = w0 ? c1 : C0;
+          L1 = w1 ? unmatched + 1 : L1, D1 = w1 ? 0u : D1, C1 = w1 ? c1 : C1;
+          nbu = relax || rget(D0, D1, t + 1) == 0;
         }
         if (!(vmask >> t & 1)) continue;
 
         // repeat match (bargain1.go:148-157)
-        if (pd != 0 && pd != wd[(r + 4) & M]) {
+        if (pd != 0 && pd != rget(D0, D1, t + 4)) {
           if (pd != rep_pd) {
+            KB_COUNT(rep);
             bool eq = false, lng = false;
             uint32_t f = 0;
             if (valid && i_l >= pd) {
-              const uint32_t a = i_l - pd;
-              eq = kb_ld32(src + a) == cv32;
-              if (eq) {
-                const uint32_t maxf = he - (i_l + 4);
-                f = kb_fwd32(src, (uint64_t)a + 4, (uint64_t)i_l + 4, maxf, lim);
-                lng = f == (uint32_t)KB_FCAP && maxf > (uint32_t)KB_FCAP;
-              }
+              const KbEval e = kb_eval(src, lim, i_l - pd, i_l, cv, he - (i_l + 4), 0u);
+              eq = e.eq4, f = e.f, lng = e.f_long;
             }
             rep_f = f;
             rep_mask = __builtin_amdgcn_ballot_w64(eq);
@@ -398,6 +497,7 @@ __global__ __launch_bounds__(64) void kb_parse(
             rep_pd = pd;
           }
           if (rep_mask >> t & 1) {
+            KB_COUNT(repm);
             uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)rep_f, (int)t);
             if (rep_long >> t & 1) end = wave_extend((uint64_t)(i - pd) + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
             add_match(i, end, i - pd, unmatched, true);
@@ -406,11 +506,11 @@ __global__ __launch_bounds__(64) void kb_parse(
 
         if (P.skip && (i & 1)) continue; // bargain1.go:159 (no slide moves the origin inside a batch chunk)
 
-        const bool nbu = wd[(r + 1) & M] == 0;
         if (unmatched > 0 || (int32_t)i >= nos || nbu) {
 #pragma unroll
           for (int q = 0; q < NT; q++) {
             if (!(okm[q] >> t & 1)) continue;
+            KB_COUNT(cand);
             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand[q], (int)t);
             uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)cf[q], (int)t);
             if (flm[q] >> t & 1) end = wave_extend((uint64_t)c + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
@@ -426,6 +526,24 @@ __global__ __launch_bounds__(64) void kb_parse(
           }
         }
       }
+
+      // ---- the batch's arrivals go to the ring; the next 64 come in from it
+      {
+        const uint32_t s0 = (b0 + lane) & M;
+        wl[s0] = L0, wd[s0] = D0, wc[s0] = C0;
+        L0 = L1, D0 = D1, C0 = C1;
+        const uint32_t s2 = (b0 + 128 + lane) & M;
+        L1 = wl[s2], D1 = wd[s2], C1 = wc[s2];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // (b0 is now the first multiple of 64 at or above n: registers hold [b0, b0 + 128), arrival n may be entry 0)
+    {
+      const uint32_t s0 = (b0 + lane) & M;
+      wl[s0] = L0, wd[s0] = D0, wc[s0] = C0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
 
     // ---- the ring goes to HBM, then the backward walk (bargain1.go:184-207)
@@ -470,6 +588,14 @@ __global__ __launch_bounds__(64) void kb_parse(
       if (lane == 0) st[top].unmatched = cu, st[top].length = cl, st[top].distance = cd;
     }
     if (lane == 0) counts[b] = stage_cap - top;
+#ifdef KB_STATS
+    if (lane == 0) {
+      atomicAdd(&kb_stats[0], (unsigned long long)st_rep), atomicAdd(&kb_stats[1], (unsigned long long)st_add);
+      atomicAdd(&kb_stats[2], (unsigned long long)st_far), atomicAdd(&kb_stats[3], (unsigned long long)st_ext);
+      atomicAdd(&kb_stats[4], (unsigned long long)st_back), atomicAdd(&kb_stats[5], (unsigned long long)st_pdfar);
+      atomicAdd(&kb_stats[6], (unsigned long long)st_cand), atomicAdd(&kb_stats[7], (unsigned long long)st_repm);
+    }
+#endif
   }
 }
 

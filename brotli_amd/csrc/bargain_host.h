@@ -4,7 +4,7 @@
 
 namespace {
 
-constexpr int kKbWavesPerCu = 16;
+constexpr int kKbWavesPerCu = 32; // 4 KiB of LDS and <= 64 VGPRs per wave
 
 struct BargainDesc {
   int nt = 0;
@@ -287,3 +287,13 @@ extern "C" int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int
   cleanup();
   return r;
 }
+
+#ifdef KB_STATS
+// Debug build only (tools/bargain_stats.sh): event counters of the search kernel since the last call.
+extern "C" int m4g_debug_bargain_stats(unsigned long long *out) {
+  unsigned long long z[8] = {0};
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(kb_stats), sizeof z));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(kb_stats), z, sizeof z));
+  return M4G_OK;
+}
+#endif

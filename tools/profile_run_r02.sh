@@ -8,15 +8,15 @@ out=gpurun_out/${1:-run}
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 step() { name=$1; shift; echo "== $name" >&2; "$@" || { echo "step $name failed (rc $?)" >&2; exit 1; }; }
-B1K="python3 bench.py --chunks 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --verify-chunks 0 --flate-chunks 0 --writer-mib 0"
+B1K="python3 bench.py --chunks 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --verify-chunks 0 --flate-chunks 0 --writer-mib 0 --bargain-chunks 0"
 pmc() { name=$1; shift; args=$1; shift
   step "pmc_$name" bash -c "timeout -s KILL 150 rocprofv3 --pmc $* -d $out/pmc_$name -- $B1K $args > $out/pmc_$name.log 2>&1"; }
 step tests   bash -c "timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $out/gpu_tests.log 2>&1"
 step smoke   bash -c "timeout -k 10 120 python __graft_entry__.py smoke > $out/smoke.log 2>&1"
 step bench   bash -c "timeout -k 10 500 python bench.py > $out/bench.json 2> $out/bench.err"
 step log     bash -c "timeout -k 10 200 python bench.py --chunks 1024 --kind log --no-end-to-end --writer-mib 0 > $out/bench_log.json 2>> $out/bench.err"
-step D       bash -c "timeout -k 10 300 python bench.py --chunks 1024 --params D --no-end-to-end --flate-chunks 0 --writer-mib 0 > $out/bench_D.json 2>> $out/bench.err"
-step trace   bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0 > $out/trace.log 2>&1"
+step D       bash -c "timeout -k 10 300 python bench.py --chunks 1024 --params D --no-end-to-end --flate-chunks 0 --writer-mib 0 --bargain-chunks 0 > $out/bench_D.json 2>> $out/bench.err"
+step trace   bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0 --bargain-chunks 0 > $out/trace.log 2>&1"
 step tracel  bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_legs -- python3 bench.py --chunks 256 --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --verify-chunks 0 > $out/trace_legs.log 2>&1"
 step trace1k bash -c "timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1k -- $B1K > $out/trace1k.log 2>&1"
 pmc fetch "" FETCH_SIZE
@@ -31,5 +31,6 @@ step kinds   bash -c "timeout -k 10 300 python tools/kind_probe.py > $out/kind_p
 step stream  bash -c "timeout -k 10 200 python tools/stream_probe.py 256 > $out/stream_probe.log 2>&1"
 step hostb   bash -c "timeout -k 10 200 python tools/hostbatch_probe.py 2048 > $out/hostbatch_probe.log 2>&1"
 step writer  bash -c "timeout -k 10 200 python tools/writer_probe.py 256 > $out/writer_probe.log 2>&1"
+step bargain bash -c "timeout -k 10 300 python tools/bargain_probe.py 512 1 2 > $out/bargain_probe.log 2>&1 && timeout -k 10 300 python tools/bargain_probe.py 512 2 2 >> $out/bargain_probe.log 2>&1"
 step compr   bash -c "timeout -k 10 200 python tools/compress_probe.py 256 > $out/compress_probe.log 2>&1"
 tail -1 "$out/bench.json" | cut -c1-400
