@@ -32,7 +32,7 @@ namespace m4g {
 constexpr int KB_WIN = 256;  // arrivals in LDS per wave (ring; positions [wlo, wlo + KB_WIN))
 constexpr int KB_BACK = 64;  // of which this many behind the current batch of 64 (the batch and the next 64 are in registers)
 constexpr int KB_FCAP = 32;  // bytes beyond the first 4 compared ahead of the walk
-constexpr int KB_MAX_TABLES = 2;
+constexpr int KB_MAX_TABLES = 3;
 
 struct BBlock {
   uint32_t job;   // chunk (stream) the block belongs to
@@ -44,12 +44,14 @@ struct BBlock {
 struct KbTable {
   uint32_t mul_lo, mul_hi; // hash = ((u & mask) * mul) >> (64 - bits)
   uint32_t mask_lo, mask_hi;
-  uint32_t bits, pad;
+  uint32_t bits;
+  uint32_t mul2; // != 0: + uint64(e) * (mul2 << 32), e = the 4 bytes after the 8 (bargain3.go:276-278)
   uint64_t chain_base_off; // element offset of this table's chain array in the chain base
 };
 
 struct KbParams {
   uint32_t max_distance, skip, overlap, block_size;
+  uint32_t tail, pad; // positions i > len(src) - tail are not hashed: 8 (bargain1.go:136), 12 (bargain3.go:153)
   KbTable t[KB_MAX_TABLES];
 };
 
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64) void kb_parse(
 
     // position 0 of the stream: the table slot of its hash holds {0, its bytes}, every other
     // slot that nobody has written holds {0, 0} (zfast.go:8-11); K1 reports both as "no predecessor"
-    const bool pos0_inserted = min(P.block_size, J.len) >= 8;
+    const bool pos0_inserted = min(P.block_size, J.len) >= P.tail;
     const uint32_t src0 = J.len >= 4 ? kb_ld32(src) : 0u;
     uint32_t h0[NT];
 #pragma unroll
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(64) void kb_parse(
       if (pos0_inserted) {
         const uint64_t u = kb_ld64(src);
         const uint64_t mul = (uint64_t)P.t[t].mul_hi << 32 | P.t[t].mul_lo, mask = (uint64_t)P.t[t].mask_hi << 32 | P.t[t].mask_lo;
-        h0[t] = (uint32_t)(((u & mask) * mul) >> (64 - P.t[t].bits));
+        const uint64_t x = P.t[t].mul2 ? (uint64_t)(kb_ld32(src + 8) * P.t[t].mul2) << 32 : 0ull;
+        h0[t] = (uint32_t)(((u & mask) * mul + x) >> (64 - P.t[t].bits));
       }
     }
 
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(64) void kb_parse(
       const uint32_t r_l = b0 + lane, i_l = hs + r_l;
       const bool inb = r_l < n;
       const float lit_l = inb ? bc[src[i_l]] : 0.f; // byteCost[src[i]], bargain1.go:127
-      const bool valid = inb && i_l + 8 <= he;        // bargain1.go:136
+      const bool valid = inb && i_l + P.tail <= he;   // bargain1.go:136, bargain3.go:153
       uint64_t cv = 0;
       if (valid) cv = kb_ld64(src + i_l);
       const uint32_t cv32 = (uint32_t)cv;
@@ -441,7 +444,8 @@ __global__ __launch_bounds__(64) void kb_parse(
           } else { // no predecessor: table entry {0, 0}, or {0, bytes of position 0} in position 0's slot
             const uint64_t mul = (uint64_t)P.t[t].mul_hi << 32 | P.t[t].mul_lo,
                            mask = (uint64_t)P.t[t].mask_hi << 32 | P.t[t].mask_lo;
-            const uint32_t h = (uint32_t)(((cv & mask) * mul) >> (64 - P.t[t].bits));
+            const uint64_t x = P.t[t].mul2 ? (uint64_t)(kb_ld32(src + i_l + 8) * P.t[t].mul2) << 32 : 0ull;
+            const uint32_t h = (uint32_t)(((cv & mask) * mul + x) >> (64 - P.t[t].bits));
             pre = i_l > 0 && i_l < P.max_distance && (cv32 == 0 || (pos0_inserted && h == h0[t]));
           }
           if (pre) {

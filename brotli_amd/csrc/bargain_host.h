@@ -8,7 +8,7 @@ constexpr int kKbWavesPerCu = 32; // 4 KiB of LDS and <= 64 VGPRs per wave
 
 struct BargainDesc {
   int nt = 0;
-  int hash_len[KB_MAX_TABLES] = {0, 0};
+  int hash_len[KB_MAX_TABLES] = {0, 0, 0};
   KbParams P{};
 };
 
@@ -20,14 +20,15 @@ int bargain_desc(const m4g_bargain_params *in, BargainDesc *d) {
   D.P.skip = in->skip ? 1u : 0u;
   D.P.block_size = in->block_size ? (uint32_t)in->block_size : 1u << 16; // writer.go:156
   if (in->max_distance < 0 || in->block_size < 0) return fail(M4G_ERR_BAD_PARAM, "negative field");
-  if (D.P.block_size < (uint32_t)KX_SUB + 7 || D.P.block_size > (1u << 24))
-    return fail(M4G_ERR_BAD_PARAM, "block_size must be 3847 .. 16 MiB");
+  if (D.P.block_size < (uint32_t)KX_SUB + 11 || D.P.block_size > (1u << 24))
+    return fail(M4G_ERR_BAD_PARAM, "block_size must be 3851 .. 16 MiB");
   auto table = [](KbTable &t, uint64_t prime, int shift, int hash_len, int bits) {
     const uint64_t mul = prime << shift, mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
     t.mul_lo = (uint32_t)mul, t.mul_hi = (uint32_t)(mul >> 32);
     t.mask_lo = (uint32_t)mask, t.mask_hi = (uint32_t)(mask >> 32);
     t.bits = (uint32_t)bits;
   };
+  D.P.tail = 8;
   if (in->variant == 1) {
     D.nt = 1, D.P.overlap = 4;
     D.hash_len[0] = 6;
@@ -37,8 +38,15 @@ int bargain_desc(const m4g_bargain_params *in, BargainDesc *d) {
     D.hash_len[0] = 5, D.hash_len[1] = 8;
     table(D.P.t[0], 889523592379ull, 24, 5, 18);
     table(D.P.t[1], 0xcf1bbcdcb7a56463ull, 0, 8, 18);
+  } else if (in->variant == 3) { // bargain3.go:20-22, 153, 268-278
+    D.nt = 3, D.P.overlap = 6, D.P.tail = 12;
+    D.hash_len[0] = 5, D.hash_len[1] = 8, D.hash_len[2] = 8;
+    table(D.P.t[0], 889523592379ull, 24, 5, 17);
+    table(D.P.t[1], 0xcf1bbcdcb7a56463ull, 0, 8, 18);
+    table(D.P.t[2], 0xcf1bbcdcb7a56463ull, 0, 8, 19);
+    D.P.t[2].mul2 = 2654435761u;
   } else {
-    return fail(M4G_ERR_BAD_PARAM, "variant must be 1 (Bargain1) or 2 (Bargain2); Bargain3's 12-byte hash is not built");
+    return fail(M4G_ERR_BAD_PARAM, "variant must be 1, 2 or 3 (Bargain1 / Bargain2 / Bargain3)");
   }
   *d = D;
   return M4G_OK;
@@ -200,7 +208,7 @@ extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, 
     hipLaunchKernelGGL((k1x_chain_build<false, true>), dim3((unsigned)(((njobs + 7) / 8) * 8 * nparts)), dim3(KX_THREADS),
                        k1x_lds_bytes(pb), st, d_src, src_total, g->d_chain + (size_t)t * g->chain_words, g->d_jobs,
                        (uint32_t *)nullptr, njobs, g->d.hash_len[t], (int)T.bits, pb, cb, 0, (const StreamInfo *)nullptr,
-                       (uint32_t *)nullptr, T.mul_lo, T.mul_hi, bs);
+                       (uint32_t *)nullptr, T.mul_lo, T.mul_hi, bs, T.mul2, g->d.P.tail - 1);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(g->ev[1], st));
@@ -211,8 +219,11 @@ extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, 
   if (g->d.nt == 1)
     hipLaunchKernelGGL(kb_parse<1>, dim3(grid), dim3(64), 0, st, d_src, src_total, g->d_chain, g->d_jobs, g->d_blocks,
                        (uint32_t)nb, g->d_bc, g->d_wld, g->d_wc, g->ws_stride, g->d_stage, g->stage_cap, g->d_counts, g->d.P);
-  else
+  else if (g->d.nt == 2)
     hipLaunchKernelGGL(kb_parse<2>, dim3(grid), dim3(64), 0, st, d_src, src_total, g->d_chain, g->d_jobs, g->d_blocks,
+                       (uint32_t)nb, g->d_bc, g->d_wld, g->d_wc, g->ws_stride, g->d_stage, g->stage_cap, g->d_counts, g->d.P);
+  else
+    hipLaunchKernelGGL(kb_parse<3>, dim3(grid), dim3(64), 0, st, d_src, src_total, g->d_chain, g->d_jobs, g->d_blocks,
                        (uint32_t)nb, g->d_bc, g->d_wld, g->d_wc, g->ws_stride, g->d_stage, g->stage_cap, g->d_counts, g->d.P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(g->ev[3], st));

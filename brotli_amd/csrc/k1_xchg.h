@@ -99,15 +99,17 @@ __global__ __launch_bounds__(256) void kx_order_selftest(uint32_t *__restrict__ 
 // XH (batches for the Bargain match finders, bargain.h): the hash multiplier is
 // an argument -- ((u << s) * prime) >> (64 - bits) of bargain1.go:210-212 is
 // ((u & mask) * (prime << s)) >> (64 - bits) -- and every job is a stream cut into
-// blocks of `batch_block` bytes (>= KX_SUB + 7) whose last 7 positions are not
-// inserted (bargain1.go:136-139), as in the STREAM form.
+// blocks of `batch_block` bytes (>= KX_SUB + 11) whose last xtail (7, or 11 for
+// Bargain3) positions are not inserted (bargain1.go:136-139, bargain3.go:153),
+// as in the STREAM form.  xmul2 != 0: Bargain3's 12-byte hash
+// (u * mul + uint64(e) * (xmul2 << 32), bargain3.go:276-278; e = the 4 bytes at i + 8).
 template <bool STREAM, bool XH = false>
 __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, uint32_t *__restrict__ table_io, int njobs,
     int hash_len, int table_bits, int part_bits, int check_bits, int dbg,
     const StreamInfo *__restrict__ si, uint32_t *__restrict__ table_out,
-    uint32_t xmul_lo, uint32_t xmul_hi, uint32_t batch_block) {
+    uint32_t xmul_lo, uint32_t xmul_hi, uint32_t batch_block, uint32_t xmul2, uint32_t xtail) {
   extern __shared__ uint32_t lds[];
   const uint32_t part_size = 1u << part_bits;
   uint32_t *table = lds;
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
   const uint32_t idx_mask = part_size - 1;
   const uint32_t cb = (uint32_t)check_bits; // <= K1_MAX_CHECK_BITS and positions << cb fit 32 bits
   const uint32_t cmask = (1u << cb) - 1;
-  const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted
+  const uint32_t tsk = XH ? xtail : 7u;
+  const uint32_t end = J.len > tsk ? J.len - tsk : 0; // positions < end are inserted
   const uint32_t ntiles = J.start < end ? (end - J.start + KX_SUB - 1) / KX_SUB : 0;
 
   // the 8 bytes at this lane's KX_PER positions of the tile at `base`
@@ -232,13 +235,20 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
         for (int j = 0; j < KX_PER; j++) {
           const uint32_t rel = my_rel + j * 64;
           const uint32_t lo = v[j].x & mask_lo, hi = v[j].y & mask_hi;
-          const uint32_t h = (__umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo) >> shift;
+          uint32_t hh = __umulhi(lo, mul_lo) + lo * mul_hi + hi * mul_lo;
           const uint32_t pos = sb + rel;
+          if (XH && xmul2) { // the high word of uint64(e) * (xmul2 << 32) is e * xmul2 mod 2^32
+            const uint64_t ea = J.src_off + pos + 8;
+            uint32_t e = 0;
+            if (ea + 4 <= src_total) __builtin_memcpy(&e, src_base + ea, 4);
+            hh += e * xmul2;
+          }
+          const uint32_t h = hh >> shift;
           // the last 7 positions of a block are never inserted (m4.go:112).  blk_end is the end of
           // the block the tile starts in; a tile can also hold the end of the call's LAST block when
           // that one is shorter than a tile (every other block is longer than a tile)
           const bool in = rel < lim && (h >> part_bits) == q &&
-                          !((STREAM || XH) && ((pos + 7 >= blk_end && pos < blk_end) || pos + 7 >= st_xend));
+                          !((STREAM || XH) && ((pos + tsk >= blk_end && pos < blk_end) || pos + 7 >= st_xend));
           // check bits of the first 4 bytes (never 0: that value marks table
           // entries whose bytes are not known); cb >= 1 (launch_k1)
           const uint32_t ck = max(1u, (v[j].x * 0x9E3779B1u) >> (32 - cb));

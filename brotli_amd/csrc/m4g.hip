@@ -277,10 +277,10 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
   if (!k1_use_sort()) {
     if (d_si)
       hipLaunchKernelGGL(k1x_chain_build<true>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), st, d_src, src_total, d_chain,
-                         d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out, 0u, 0u, 0u);
+                         d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out, 0u, 0u, 0u, 0u, 7u);
     else
       hipLaunchKernelGGL(k1x_chain_build<false>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), st, d_src, src_total, d_chain,
-                         d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out, 0u, 0u, 0u);
+                         d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out, 0u, 0u, 0u, 0u, 7u);
   } else if (d_si)
     hipLaunchKernelGGL(k1_chain_build<true>, g1, dim3(K1_THREADS), k1_lds_bytes(pb), st, d_src, src_total, d_chain,
                        d_jobs, d_table_io, njobs, p.hash_len, p.table_bits, pb, cb, 0, d_si, d_table_out);
@@ -1353,7 +1353,7 @@ extern "C" int m4g_debug_k1_only(m4g_batch *b, const uint8_t *d_src, uint64_t sr
                          b->W.d_chain, b->W.d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr);
     else
       hipLaunchKernelGGL(k1x_chain_build<false>, g1, dim3(KX_THREADS), k1x_lds_bytes(pb), nullptr, d_src, src_total,
-                         b->W.d_chain, b->W.d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr, 0u, 0u, 0u);
+                         b->W.d_chain, b->W.d_jobs, nullptr, njobs, b->p.hash_len, b->p.table_bits, pb, 5, dbg, nullptr, nullptr, 0u, 0u, 0u, 0u, 7u);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev[1], nullptr));
   HIP_TRY(hipEventSynchronize(b->ev[1]));

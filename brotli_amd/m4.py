@@ -599,17 +599,17 @@ def brotli_compress(data, block_size: int = 1 << 16, device: int = 0, **m4_field
 
 def writer_v2_match_finder(level: int) -> dict:
     """The MatchFinder brotli.NewWriterV2(dst, level) builds for the levels that use Bargain1 / Bargain2
-    (writer.go:142-148), as keyword arguments of bargain_find_blocks / BargainPlan."""
-    table = {5: (1, False), 6: (1, False), 7: (2, True), 8: (2, False)}
+    (writer.go:142-150), as keyword arguments of bargain_find_blocks / BargainPlan."""
+    table = {5: (1, False), 6: (1, False), 7: (2, True), 8: (2, False), 9: (3, False)}
     if level not in table:
-        raise M4GError(f"NewWriterV2 level {level}: only levels 5-8 (Bargain1, Bargain2) are built")
+        raise M4GError(f"NewWriterV2 level {level}: levels 5-9 (Bargain1 / Bargain2 / Bargain3) are built")
     v, skip = table[level]
     return {"variant": v, "MaxDistance": 1 << 20, "Skip": skip, "BlockSize": 1 << 16}
 
 
 def brotli_compress_v2(data, level: int = 5, device: int = 0) -> bytes:
-    """w := brotli.NewWriterV2(dst, level); w.Write(data); w.Close() for level 5-8 (writer.go:126-161):
-    matchfinder.Writer{Bargain1 | Bargain2, &Encoder{}, BlockSize 1 << 16} with the match finder
+    """w := brotli.NewWriterV2(dst, level); w.Write(data); w.Close() for level 5-9 (writer.go:126-161):
+    matchfinder.Writer{Bargain1 | Bargain2 | Bargain3, &Encoder{}, BlockSize 1 << 16} with the match finder
     (m4g_bargain_find_blocks) and both passes of Encoder.Encode (m4g_brotli_encode_blocks) on the GPU."""
     a = _as_u8(data)
     kw = writer_v2_match_finder(level)

@@ -433,10 +433,11 @@ int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uin
                                  m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
                                  m4g_histo *d_histos, void *hip_stream);
 
-/* ---- matchfinder.Bargain1 / Bargain2 ------------------------
+/* ---- matchfinder.Bargain1 / Bargain2 / Bargain3 -------------
  * The shortest-path match finders that brotli.NewWriterV2 plugs into
- * matchfinder.Writer for levels 5-8 (writer.go:142-148; Bargain1:
- * matchfinder/bargain1.go:15-31, FindMatches :38-208; Bargain2: bargain2.go).
+ * matchfinder.Writer for levels 5-9 (writer.go:142-150; Bargain1:
+ * matchfinder/bargain1.go:15-31, FindMatches :38-208; Bargain2: bargain2.go;
+ * Bargain3: bargain3.go).
  * The Writer hands FindMatches one block of BlockSize bytes at a time
  * (matchfinder.go:59-93); what connects the calls is the hash table and the
  * history.  Here a CHUNK is one such stream (fresh state: Reset(),
@@ -446,13 +447,12 @@ int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uin
  * Output: the Match lists of all blocks in (chunk, block) order and
  * block_off[k] = index of block k's first Match (nblocks + 1 entries; blocks of
  * chunk c: ceil(len_c / block_size), m4g_bargain_block_count() sums them).
- * Bargain3 (12-byte hash, bargain3.go) is not built: variant 3 is
- * M4G_ERR_BAD_PARAM. */
+ */
 typedef struct m4g_bargain_params {
-  int32_t variant;      /* 1 = Bargain1, 2 = Bargain2 */
+  int32_t variant;      /* 1 = Bargain1, 2 = Bargain2, 3 = Bargain3 */
   int32_t max_distance; /* MaxDistance; 0 = 1 << 16 (bargain1.go:39-41); NewWriterV2 uses 1 << 20 */
   int32_t skip;         /* Skip (bargain1.go:20-22, 159) */
-  int32_t block_size;   /* Writer.BlockSize; 0 = 1 << 16 (writer.go:156); 3847 .. 1 << 24 */
+  int32_t block_size;   /* Writer.BlockSize; 0 = 1 << 16 (writer.go:156); 3851 .. 1 << 24 */
 } m4g_bargain_params;
 typedef struct m4g_bargain m4g_bargain;
 

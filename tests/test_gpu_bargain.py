@@ -24,7 +24,7 @@ def same(data, variant=1, md=1 << 20, skip=False, bs=1 << 16):
     assert bad.size == 0, (int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("skip", [False, True])
 def test_opticks(variant, skip):
     """brotli_test.go:886-932: the reference's own test input and settings (MaxDistance 1 << 20, 1 << 16 blocks)."""
@@ -32,7 +32,7 @@ def test_opticks(variant, skip):
     same(data, variant, 1 << 20, skip)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_kinds(variant):
     rng = np.random.default_rng(5)
     same(text(300000, 3), variant, bs=4096)
@@ -48,12 +48,13 @@ def test_kinds(variant):
 
 
 def test_tiny_and_edges():
-    for n in (1, 7, 8, 9, 63, 64, 65, 4095, 4096, 4097):
-        same(text(n, n), 1, bs=4096)
+    for n in (1, 7, 8, 9, 11, 12, 13, 63, 64, 65, 4095, 4096, 4097):
+        for variant in (1, 3):
+            same(text(n, n), variant, bs=4096)
     got, off = m4.bargain_find_blocks(b"", 1)
     assert got.shape == (0, 3) and off.tolist() == [0]
     with pytest.raises(m4.M4GError):
-        m4.bargain_find_blocks(b"x" * 100, 3)       # Bargain3 is not built
+        m4.bargain_find_blocks(b"x" * 100, 4)
     with pytest.raises(m4.M4GError):
         m4.bargain_find_blocks(b"x" * 100, 1, BlockSize=1000)
 
@@ -65,6 +66,8 @@ def test_stream_position_zero_is_a_candidate():
     same(head + text(5000, 12) + head + text(3000, 13), 1, bs=4096)
     same(bytes(8) + text(5000, 12) + bytes(12) + text(3000, 13), 1, bs=4096)
     same(b"\0\0\0\0abcd" + text(5000, 12) + bytes(12) + text(3000, 13), 2, bs=4096)
+    same(head + b"ab" + text(5000, 12) + head + b"ab" + text(3000, 13), 3, bs=4096)
+    same(bytes(12) + text(5000, 12) + bytes(16) + text(3000, 13), 3, bs=4096)
 
 
 def test_batch_of_streams_device():
@@ -121,9 +124,9 @@ def oracle_writer_v2(data: bytes, level: int) -> bytes:
     return bytes(out)
 
 
-@pytest.mark.parametrize("level", [5, 6, 7, 8])
+@pytest.mark.parametrize("level", [5, 6, 7, 8, 9])
 def test_new_writer_v2_levels_on_gpu(level):
-    """NewWriterV2(dst, 5..8) end to end on the GPU: same bytes as the restated Writer, and they decode."""
+    """NewWriterV2(dst, 5..9) end to end on the GPU: same bytes as the restated Writer, and they decode."""
     data = open(OPTICKS, "rb").read()
     for blob in (data, data[:3 << 16], data[:70000], b""):
         got = m4.brotli_compress_v2(blob, level)
