@@ -315,18 +315,46 @@ __global__ __launch_bounds__(64) void kb_parse(
       return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(read_c(k))));
     };
 
-    // addMatch (bargain1.go:86-108); all arguments wave-uniform.  The loop runs from m.End down and
-    // stops at the first arrival that is at least as cheap: per 64 arrivals, one ballot finds it.
-    auto add_match = [&](uint32_t start, uint32_t end, uint32_t match, uint32_t unmatched, bool repeat) {
+    // addMatch (bargain1.go:86-108) in block coordinates; all arguments wave-uniform: the match starts at
+    // arrival ks (= m.Start - historyLen), ends at arrival k_top, dcost = float32(bits.Len(distance)) or 0
+    // for a repeat.  The reference's loop runs from m.End down and stops at the first arrival that is at least
+    // as cheap: per 64 arrivals, one compare and one ballot find it.
+    // start_cost = the cost of arrival ks at the time of the call (0 for ks = 0); top_first: look at arrival
+    // k_top alone before the rest (the loop stops there when a match found at the previous position already
+    // covers this one, which is the rule for the backward-extended form).
+    auto add_match = [&](uint32_t ks, float start_cost, int32_t k_top, uint32_t dist, uint32_t unmatched, float dcost,
+                         bool top_first) {
       KB_COUNT(add);
-      const uint32_t ks = start - hs;
-      const float start_cost = ks > 0 ? uread_c(ks) : 0.f;
       float cost = start_cost + 4.0f; // baseMatchCost, pathfinder.go:64
       cost = cost + (float)kb_bitlen(unmatched);
-      cost = cost + (repeat ? 0.f : (float)kb_bitlen(start - match));
-      const uint32_t dist = start - match;
-      const int32_t k_lo = (int32_t)ks + 3, k_top = (int32_t)(end - hs);
+      cost = cost + dcost;
+      const int32_t k_lo = (int32_t)ks + 3;
       const int32_t r_lo = (int32_t)b0, r_hi = (int32_t)b0 + 127;
+      if (top_first && k_top >= k_lo && (uint32_t)(k_top - r_lo) < 128u) {
+        const float ct = __uint_as_float(rget(__float_as_uint(C0), __float_as_uint(C1), (uint32_t)(k_top - r_lo)));
+        if (ct > 0.f && ct <= cost) return;
+      }
+      if (k_lo >= r_lo && k_top <= r_lo + 63) { // the whole range is in the first register row
+        const int32_t k0 = r_lo + (int32_t)lane;
+        const bool in0 = k0 >= k_lo && k0 <= k_top;
+        const unsigned long long sm0 = __builtin_amdgcn_ballot_w64(in0 && C0 > 0.f && C0 <= cost);
+        const int32_t hi0 = sm0 ? 63 - (int32_t)__builtin_clzll(sm0) : -1;
+        const bool w0 = in0 && (int32_t)lane > hi0;
+        L0 = w0 ? (uint32_t)k0 - ks : L0, D0 = w0 ? dist : D0, C0 = w0 ? cost : C0;
+        return;
+      }
+      if (k_lo >= r_lo && k_top <= r_hi) { // the whole range is in registers: no branch below
+        const int32_t k0 = r_lo + (int32_t)lane, k1 = k0 + 64;
+        const bool in1 = k1 >= k_lo && k1 <= k_top, in0 = k0 >= k_lo && k0 <= k_top;
+        const unsigned long long sm1 = __builtin_amdgcn_ballot_w64(in1 && C1 > 0.f && C1 <= cost);
+        const unsigned long long sm0 = __builtin_amdgcn_ballot_w64(in0 && C0 > 0.f && C0 <= cost);
+        const int32_t hi1 = sm1 ? 63 - (int32_t)__builtin_clzll(sm1) : -1, hi0 = sm0 ? 63 - (int32_t)__builtin_clzll(sm0) : -1;
+        const bool w1 = in1 && (int32_t)lane > hi1;
+        const bool w0 = in0 && sm1 == 0 && (int32_t)lane > hi0;
+        L1 = w1 ? (uint32_t)k1 - ks : L1, D1 = w1 ? dist : D1, C1 = w1 ? cost : C1;
+        L0 = w0 ? (uint32_t)k0 - ks : L0, D0 = w0 ? dist : D0, C0 = w0 ? cost : C0;
+        return;
+      }
       bool stopped = false;
       // arrivals [lo, top] outside the register window, 64 per step
       auto far = [&](int32_t top_k, int32_t lo_k) {
@@ -428,7 +456,8 @@ __global__ __launch_bounds__(64) void kb_parse(
       uint64_t cv = 0;
       if (valid) cv = kb_ld64(src + i_l);
       const uint32_t cv32 = (uint32_t)cv;
-      uint32_t cand[NT], cf[NT], cb[NT];
+      uint32_t cdist[NT], cktop[NT], cb[NT]; // distance, arrival index of the match end, backward extension
+      float cdc[NT];                         // float32(bits.Len(distance)), bargain1.go:94
       unsigned long long okm[NT], flm[NT], blm[NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) {
@@ -448,13 +477,17 @@ __global__ __launch_bounds__(64) void kb_parse(
             const uint32_t h = (uint32_t)(((cv & mask) * mul + x) >> (64 - P.t[t].bits));
             pre = i_l > 0 && i_l < P.max_distance && (cv32 == 0 || (pos0_inserted && h == h0[t]));
           }
+#if defined(KB_EXP) && KB_EXP >= 3
+          pre = false;
+#endif
           if (pre) {
             const KbEval e = kb_eval(src, lim, c, i_l, cv, he - (i_l + 4), min(r_l, c));
             ok = e.eq4; // bargain1.go:167
             f = e.f, f_long = e.f_long, bl = e.bl, b_long = e.b_long;
           }
         }
-        cand[t] = c, cf[t] = f, cb[t] = bl;
+        cdist[t] = i_l - c, cktop[t] = r_l + 4 + f, cb[t] = bl;
+        cdc[t] = (float)kb_bitlen(i_l - c);
         okm[t] = __builtin_amdgcn_ballot_w64(ok);
         flm[t] = __builtin_amdgcn_ballot_w64(f_long);
         blm[t] = __builtin_amdgcn_ballot_w64(b_long);
@@ -474,6 +507,9 @@ __global__ __launch_bounds__(64) void kb_parse(
         const uint32_t unmatched = a_dist == 0 ? a_len : 0u;
         uint32_t pd = 0;
         if (unmatched != 0 && r > unmatched) pd = uread_d(r - unmatched);
+#if defined(KB_EXP) && KB_EXP >= 2
+        pd = 0;
+#endif
         const float c1 = a_cost + __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lit_l), (int)t));
         bool nbu;
         {
@@ -504,28 +540,39 @@ __global__ __launch_bounds__(64) void kb_parse(
             KB_COUNT(repm);
             uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)rep_f, (int)t);
             if (rep_long >> t & 1) end = wave_extend((uint64_t)(i - pd) + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
-            add_match(i, end, i - pd, unmatched, true);
+            add_match(r, a_cost, (int32_t)(end - hs), pd, unmatched, 0.f, false);
           }
         }
 
         if (P.skip && (i & 1)) continue; // bargain1.go:159 (no slide moves the origin inside a batch chunk)
 
+#if defined(KB_EXP) && KB_EXP >= 1
+        if (false) {
+#else
         if (unmatched > 0 || (int32_t)i >= nos || nbu) {
+#endif
 #pragma unroll
           for (int q = 0; q < NT; q++) {
             if (!(okm[q] >> t & 1)) continue;
             KB_COUNT(cand);
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand[q], (int)t);
-            uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)cf[q], (int)t);
-            if (flm[q] >> t & 1) end = wave_extend((uint64_t)c + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
+            const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)cdist[q], (int)t);
+            int32_t k_top = __builtin_amdgcn_readlane((int)cktop[q], (int)t);
             uint32_t delta = (uint32_t)__builtin_amdgcn_readlane((int)cb[q], (int)t);
-            if (blm[q] >> t & 1) delta = wave_back(i, c, min(r, c));
-            if (delta == 0) {
-              add_match(i, end, c, unmatched, false);
-            } else { // extended backwards: with and without the extra (bargain1.go:172-178)
-              add_match(i - delta, end, c - delta, unmatched > delta ? unmatched - delta : 0u, false);
-              add_match(i, end, c, unmatched, false);
+            const float dcost = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cdc[q]), (int)t));
+            if ((flm[q] | blm[q]) >> t & 1) { // extensions beyond what phase A compared
+              const uint32_t c = i - dist;
+              if (flm[q] >> t & 1)
+                k_top = (int32_t)(wave_extend((uint64_t)c + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP) - hs);
+              if (blm[q] >> t & 1) delta = wave_back(i, c, min(r, c));
             }
+            // extended backwards: with and without the extra (bargain1.go:172-178)
+            if (delta != 0)
+              add_match(r - delta, r > delta ? uread_c(r - delta) : 0.f, k_top, dist, unmatched > delta ? unmatched - delta : 0u,
+                        dcost, true);
+            // (the extended form may have rewritten arrival r when delta >= 3: read its cost again)
+            add_match(r, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(C0), (int)t)), k_top, dist,
+                      unmatched, dcost, false);
+            const uint32_t end = hs + (uint32_t)k_top;
             nos = max(nos, max((int32_t)i + 1, (int32_t)end - (int32_t)P.overlap));
           }
         }

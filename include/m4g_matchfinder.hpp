@@ -104,6 +104,38 @@ private:
   std::vector<m4g_match> buf_;
 };
 
+// matchfinder.Bargain1 / Bargain2 / Bargain3 (bargain1.go:15-31, bargain2.go, bargain3.go) on an MI355X.
+// The reference's FindMatches takes one block per call and its state is the hash table and history; one block
+// is one wavefront's work, so the GPU form takes the whole stream: FindMatchesBlocks returns what the
+// FindMatches calls of matchfinder.Writer{MatchFinder: &BargainN{MaxDistance, Skip}, BlockSize} produce for
+// src (matchfinder.go:59-93), the Match list of block b in dst[blockOff[b] .. blockOff[b+1]).
+class Bargain {
+public:
+  int Variant = 1; // 1, 2, 3 = Bargain1, Bargain2, Bargain3
+  int MaxDistance = 0;
+  bool Skip = false;
+  int Device = 0;
+
+  std::vector<Match> &FindMatchesBlocks(std::vector<Match> &dst, const uint8_t *src, size_t n, size_t blockSize,
+                                        std::vector<size_t> &blockOff) {
+    m4g_bargain_params p{Variant, MaxDistance, Skip ? 1 : 0, (int32_t)blockSize};
+    const size_t bs = blockSize ? blockSize : (size_t)1 << 16;
+    const size_t nblocks = (n + bs - 1) / bs;
+    std::vector<m4g_match> buf(n / 3 + 2 * nblocks + 8);
+    std::vector<uint64_t> off(nblocks + 1, 0);
+    const int64_t r = m4g_bargain_find_blocks(&p, Device, src, n, buf.data(), buf.size(), off.data());
+    if (r < 0)
+      throw std::runtime_error(std::string("m4g_bargain_find_blocks: ") + m4g_strerror((int)r) + " (" +
+                               m4g_last_error() + ")");
+    const size_t base = dst.size();
+    dst.reserve(base + (size_t)r);
+    for (int64_t k = 0; k < r; k++) dst.push_back(Match{buf[k].unmatched, buf[k].length, buf[k].distance});
+    blockOff.assign(nblocks + 1, base);
+    for (size_t b = 0; b <= nblocks; b++) blockOff[b] = base + (size_t)off[b];
+    return dst;
+  }
+};
+
 struct AutoReset : MatchFinder {
   MatchFinder *Inner = nullptr;
   std::vector<Match> &FindMatches(std::vector<Match> &dst, const uint8_t *src, size_t n) override {

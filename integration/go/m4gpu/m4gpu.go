@@ -347,3 +347,34 @@ func (w *Writer) Reset(newDest io.Writer) {
 	w.err = nil
 	w.Dest = newDest
 }
+
+// BargainBlocks returns the Match lists that the FindMatches calls of
+// matchfinder.Writer{MatchFinder: &matchfinder.BargainN{MaxDistance: maxDistance, Skip: skip}, BlockSize: blockSize}
+// produce for data (variant N = 1, 2, 3; bargain1.go:38-208, bargain2.go, bargain3.go; matchfinder.go:59-93):
+// matches[off[k]:off[k+1]] is block k.  brotli.NewWriterV2 levels 5-9 use these finders with MaxDistance 1 << 20 and
+// BlockSize 1 << 16 (writer.go:142-156); encode block k with Encoder.Encode(dst, block, matches[off[k]:off[k+1]], last).
+func BargainBlocks(data []byte, variant, maxDistance int, skip bool, blockSize int) (matches []matchfinder.Match, off []uint64) {
+	if blockSize == 0 {
+		blockSize = 1 << 16
+	}
+	nb := (len(data) + blockSize - 1) / blockSize
+	off = make([]uint64, nb+1)
+	if len(data) == 0 {
+		return nil, off
+	}
+	p := C.m4g_bargain_params{variant: C.int32_t(variant), max_distance: C.int32_t(maxDistance), block_size: C.int32_t(blockSize)}
+	if skip {
+		p.skip = 1
+	}
+	raw := make([]C.m4g_match, len(data)/3+2*nb+8)
+	n := C.m4g_bargain_find_blocks(&p, 0, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)),
+		&raw[0], C.size_t(len(raw)), (*C.uint64_t)(unsafe.Pointer(&off[0])))
+	if n < 0 {
+		fail("m4g_bargain_find_blocks", C.int(n))
+	}
+	matches = make([]matchfinder.Match, n)
+	for i := range matches {
+		matches[i] = matchfinder.Match{Unmatched: int(raw[i].unmatched), Length: int(raw[i].length), Distance: int(raw[i].distance)}
+	}
+	return matches, off
+}

@@ -75,6 +75,36 @@ int main() {
     std::puts("FAIL writer (token limits)");
     return 1;
   }
+  // Bargain1 over the same bytes in 8192-byte blocks: every block's list tiles its block, copies equal bytes
+  // (the Python tests compare the lists with the restated finder)
+  {
+    matchfinder::Bargain bg;
+    bg.MaxDistance = 1 << 16;
+    std::vector<matchfinder::Match> bm;
+    std::vector<size_t> boff;
+    bg.FindMatchesBlocks(bm, data.data(), data.size(), 8192, boff);
+    const size_t nb = (data.size() + 8191) / 8192;
+    if (boff.size() != nb + 1) {
+      std::puts("FAIL bargain (blocks)");
+      return 1;
+    }
+    for (size_t b = 0; b < nb; b++) {
+      size_t pos = b * 8192;
+      for (size_t k = boff[b]; k < boff[b + 1]; k++) {
+        pos += bm[k].Unmatched;
+        for (int t = 0; t < bm[k].Length; t++)
+          if (bm[k].Distance <= 0 || (size_t)bm[k].Distance > pos + t || data[pos + t] != data[pos + t - bm[k].Distance]) {
+            std::puts("FAIL bargain (copy)");
+            return 1;
+          }
+        pos += bm[k].Length;
+      }
+      if (pos != std::min(data.size(), (b + 1) * 8192)) {
+        std::puts("FAIL bargain (tiling)");
+        return 1;
+      }
+    }
+  }
   std::puts("ok");
   return 0;
 }
