@@ -506,7 +506,10 @@ __global__ __launch_bounds__(64) void kb_parse(
         const float n_cost = __uint_as_float(rget(__float_as_uint(C0), __float_as_uint(C1), t + 1));
         const uint32_t unmatched = a_dist == 0 ? a_len : 0u;
         uint32_t pd = 0;
-        if (unmatched != 0 && r > unmatched) pd = uread_d(r - unmatched);
+        if (unmatched != 0 && r > unmatched) { // arrival r - unmatched is below r: first register row, or older
+          const uint32_t kb = r - unmatched;
+          pd = kb >= b0 ? (uint32_t)__builtin_amdgcn_readlane((int)D0, (int)(kb - b0)) : uread_d(kb);
+        }
 #if defined(KB_EXP) && KB_EXP >= 2
         pd = 0;
 #endif
@@ -523,18 +526,22 @@ __global__ __launch_bounds__(64) void kb_parse(
 
         // repeat match (bargain1.go:148-157)
         if (pd != 0 && pd != rget(D0, D1, t + 4)) {
-          if (pd != rep_pd) {
+          if (pd != rep_pd) { // the 4-byte probe at all 64 positions of the batch: one load
             KB_COUNT(rep);
-            bool eq = false, lng = false;
-            uint32_t f = 0;
-            if (valid && i_l >= pd) {
-              const KbEval e = kb_eval(src, lim, i_l - pd, i_l, cv, he - (i_l + 4), 0u);
-              eq = e.eq4, f = e.f, lng = e.f_long;
-            }
-            rep_f = f;
+            const bool eq = valid && i_l >= pd && kb_ld32(src + (i_l - pd)) == cv32;
             rep_mask = __builtin_amdgcn_ballot_w64(eq);
-            rep_long = __builtin_amdgcn_ballot_w64(lng);
             rep_pd = pd;
+            rep_long = 0;
+            if (rep_mask) { // (rare: 6 probes in 10000 hit) how far the matches run
+              bool lng = false;
+              uint32_t f = 0;
+              if (eq) {
+                const KbEval e = kb_eval(src, lim, i_l - pd, i_l, cv, he - (i_l + 4), 0u);
+                f = e.f, lng = e.f_long;
+              }
+              rep_f = f;
+              rep_long = __builtin_amdgcn_ballot_w64(lng);
+            }
           }
           if (rep_mask >> t & 1) {
             KB_COUNT(repm);
