@@ -299,6 +299,27 @@ extern "C" int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int
   return r;
 }
 
+// w := brotli.NewWriterV2(dst, level); w.Write(src); w.Close() for the levels whose MatchFinder is one of the
+// Bargain finders (writer.go:126-161): level 5, 6 Bargain1, 7 Bargain2 with Skip, 8 Bargain2, 9 (and above) Bargain3,
+// MaxDistance 1 << 20, BlockSize 1 << 16, Encoder &brotli.Encoder{}.  Host memory in, the brotli stream out.
+extern "C" int64_t m4g_brotli_compress_v2(int level, int device, const uint8_t *src, size_t n, uint8_t *out, size_t out_cap) {
+  if ((!src && n) || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (level > 9) level = 9; // writer.go:129-131
+  if (level < 5)
+    return fail(M4G_ERR_BAD_PARAM, "NewWriterV2 levels 0-4 use ZFast / ZDFast / ZM / Trio, which are not built (levels 5-9 are)");
+  m4g_bargain_params p{};
+  p.variant = level <= 6 ? 1 : (level <= 8 ? 2 : 3);
+  p.max_distance = 1 << 20;
+  p.skip = level == 7 ? 1 : 0;
+  p.block_size = 1 << 16;
+  const size_t bs = (size_t)p.block_size, nb = (n + bs - 1) / bs;
+  std::vector<m4g_match> matches(n / 3 + 2 * nb + 8);
+  std::vector<uint64_t> off(nb + 1, 0);
+  const int64_t nm = m4g_bargain_find_blocks(&p, device, src, n, matches.data(), matches.size(), off.data());
+  if (nm < 0) return nm;
+  return m4g_brotli_encode_blocks(device, src, n, bs, matches.data(), off.data(), out, out_cap);
+}
+
 #ifdef KB_STATS
 // Debug build only (tools/bargain_stats.sh): event counters of the search kernel since the last call.
 extern "C" int m4g_debug_bargain_stats(unsigned long long *out) {

@@ -48,7 +48,7 @@ EXPORTS = [
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
     "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
     "m4g_bargain_create", "m4g_bargain_destroy", "m4g_bargain_block_count", "m4g_bargain_run_device",
-    "m4g_bargain_last_timings", "m4g_bargain_find_blocks",
+    "m4g_bargain_last_timings", "m4g_bargain_find_blocks", "m4g_brotli_compress_v2",
 ]
 
 _LIB = None
@@ -144,6 +144,8 @@ def lib():
         L.m4g_bargain_last_timings.argtypes = [vp, vp, ctypes.c_int]
         L.m4g_bargain_find_blocks.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, vp, sz, vp, sz, vp]
         L.m4g_bargain_find_blocks.restype = ctypes.c_int64
+        L.m4g_brotli_compress_v2.argtypes = [ctypes.c_int, ctypes.c_int, vp, sz, vp, sz]
+        L.m4g_brotli_compress_v2.restype = ctypes.c_int64
         L.m4g_host_alloc.argtypes = [sz]
         L.m4g_host_alloc.restype = vp
         L.m4g_host_free.argtypes = [vp]
@@ -609,20 +611,15 @@ def writer_v2_match_finder(level: int) -> dict:
 
 def brotli_compress_v2(data, level: int = 5, device: int = 0) -> bytes:
     """w := brotli.NewWriterV2(dst, level); w.Write(data); w.Close() for level 5-9 (writer.go:126-161):
-    matchfinder.Writer{Bargain1 | Bargain2 | Bargain3, &Encoder{}, BlockSize 1 << 16} with the match finder
-    (m4g_bargain_find_blocks) and both passes of Encoder.Encode (m4g_brotli_encode_blocks) on the GPU."""
+    matchfinder.Writer{Bargain1 | Bargain2 | Bargain3, &Encoder{}, BlockSize 1 << 16} with the match finder and both
+    passes of Encoder.Encode on the GPU (m4g_brotli_compress_v2)."""
     a = _as_u8(data)
-    kw = writer_v2_match_finder(level)
-    bs = kw["BlockSize"]
-    matches, off = bargain_find_blocks(a, device=device, **kw)
-    cap = a.size + (a.size // bs + 2) * 1024 + 64
+    cap = a.size + (a.size // (1 << 16) + 2) * 1024 + 64
     buf = np.zeros(cap, dtype=np.uint8)
-    m = np.ascontiguousarray(matches, dtype=np.uint32)
-    r = lib().m4g_brotli_encode_blocks(device, a.ctypes.data if a.size else None, a.size, bs,
-                                       m.ctypes.data if m.size else None, off.ctypes.data, buf.ctypes.data, cap)
-    _check(r, "m4g_brotli_encode_blocks")
+    r = lib().m4g_brotli_compress_v2(level, device, a.ctypes.data if a.size else None, a.size, buf.ctypes.data, cap)
+    _check(r, "m4g_brotli_compress_v2")
     if r < 0:
-        raise M4GError(f"m4g_brotli_encode_blocks: stream_cap too small, need {-r - STREAM_NEEDED_BIAS}")
+        raise M4GError(f"m4g_brotli_compress_v2: out_cap too small, need {-r - STREAM_NEEDED_BIAS}")
     return buf[:r].tobytes()
 
 

@@ -378,3 +378,18 @@ func BargainBlocks(data []byte, variant, maxDistance int, skip bool, blockSize i
 	}
 	return matches, off
 }
+
+// CompressV2 is w := brotli.NewWriterV2(dst, level); w.Write(data); w.Close() for levels 5-9 (writer.go:126-161)
+// with match finder and encoder on the GPU; it returns the brotli stream.
+func CompressV2(data []byte, level int) []byte {
+	out := make([]byte, len(data)+(len(data)>>16+2)*1024+64)
+	var src *C.uint8_t
+	if len(data) > 0 {
+		src = (*C.uint8_t)(unsafe.Pointer(&data[0]))
+	}
+	n := C.m4g_brotli_compress_v2(C.int(level), 0, src, C.size_t(len(data)), (*C.uint8_t)(unsafe.Pointer(&out[0])), C.size_t(len(out)))
+	if n < 0 {
+		fail("m4g_brotli_compress_v2", C.int(n))
+	}
+	return out[:n]
+}

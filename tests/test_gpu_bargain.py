@@ -132,3 +132,7 @@ def test_new_writer_v2_levels_on_gpu(level):
         got = m4.brotli_compress_v2(blob, level)
         assert got == oracle_writer_v2(blob, level)
         assert brotli_decompress(got, len(blob)) == blob
+    with pytest.raises(m4.M4GError):
+        m4.brotli_compress_v2(data[:1000], 4)   # ZFast .. Trio are not built
+    if level == 9:
+        assert m4.brotli_compress_v2(data[:70000], 11) == m4.brotli_compress_v2(data[:70000], 9)  # writer.go:129-131
