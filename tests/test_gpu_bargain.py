@@ -45,6 +45,7 @@ def test_kinds(variant):
     same(text(40000, 9) + bytes(30000) + text(40000, 9), variant, bs=16384)
     same(text(100000, 10), variant, md=0, bs=4096)                                # default MaxDistance 1 << 16
     same(text(100000, 11), variant, md=5000, bs=4096)
+    same(text(600000, 14), variant, bs=1 << 18)                                   # blocks longer than the Writer's default
 
 
 def test_tiny_and_edges():
