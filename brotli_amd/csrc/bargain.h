@@ -670,4 +670,22 @@ __global__ __launch_bounds__(256) void kb_compact(const m4g_match *__restrict__ 
   for (uint32_t k = threadIdx.x; k < c * 3; k += 256) d[k] = s[k];
 }
 
+// Literal runs of K5_HUGE bytes or more, per block Match list: the list k5b_long_literals counts (in the batch
+// pipeline k4_compact builds it).  One thread per block.
+__global__ __launch_bounds__(64) void kb_long_runs(const m4g_match *__restrict__ m, const uint64_t *__restrict__ off,
+                                                   uint32_t njobs, LongRun *__restrict__ runs, uint32_t *__restrict__ nruns,
+                                                   uint32_t cap) {
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= njobs) return;
+  uint32_t pos = 0;
+  for (uint64_t k = off[j]; k < off[j + 1]; k++) {
+    const uint32_t u = m[k].unmatched, l = m[k].length;
+    if (u >= K5_HUGE) {
+      const uint32_t idx = atomicAdd(nruns, 1u);
+      if (idx < cap) runs[idx] = LongRun{j, pos, u, 0};
+    }
+    pos += u + l;
+  }
+}
+
 } // namespace m4g

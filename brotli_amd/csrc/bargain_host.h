@@ -61,6 +61,8 @@ struct m4g_bargain {
   size_t chain_words = 0; // per table
   uint32_t nwaves = 0, ws_stride = 0, stage_cap = 0;
   Job *d_jobs = nullptr, *h_jobs = nullptr;
+  Job *d_k1jobs = nullptr, *h_k1jobs = nullptr; // K1 works on segments of long streams (table priming)
+  size_t max_k1jobs = 0, seg_bytes = 0;
   BBlock *d_blocks = nullptr, *h_blocks = nullptr;
   uint32_t *d_chain = nullptr, *d_counts = nullptr;
   float *d_bc = nullptr, *d_wc = nullptr;
@@ -76,6 +78,8 @@ extern "C" void m4g_bargain_destroy(m4g_bargain *g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
   (void)hipFree(g->d_jobs);
+  (void)hipFree(g->d_k1jobs);
+  (void)hipHostFree(g->h_k1jobs);
   (void)hipFree(g->d_blocks);
   (void)hipFree(g->d_chain);
   (void)hipFree(g->d_counts);
@@ -126,7 +130,13 @@ extern "C" int m4g_bargain_create(const m4g_bargain_params *params, int device, 
   g->stage_cap = d.P.block_size / 3 + 2;
   bool ok = true;
   auto dev = [&](auto **p, size_t bytes) { ok = ok && hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(bytes, 256)) == hipSuccess; };
+  // a stream longer than 1.5 segments is cut into segments of whole blocks for K1; each segment first inserts the
+  // max_distance bytes before it (a predecessor further back is rejected by bargain1.go:166 whether found or not)
+  g->seg_bytes = std::max<size_t>(4 * (size_t)d.P.max_distance, (size_t)4 << 20);
+  g->seg_bytes = (g->seg_bytes + d.P.block_size - 1) / d.P.block_size * d.P.block_size;
+  g->max_k1jobs = max_chunks + max_total_bytes / g->seg_bytes + 1;
   dev(&g->d_jobs, max_chunks * sizeof(Job));
+  dev(&g->d_k1jobs, g->max_k1jobs * sizeof(Job));
   dev(&g->d_blocks, g->max_blocks * sizeof(BBlock));
   dev(&g->d_chain, g->chain_words * 4 * (size_t)d.nt);
   dev(&g->d_counts, g->max_blocks * 4);
@@ -136,6 +146,7 @@ extern "C" int m4g_bargain_create(const m4g_bargain_params *params, int device, 
   dev(&g->d_stage, g->max_blocks * (size_t)g->stage_cap * sizeof(m4g_match));
   dev(&g->d_off, (g->max_blocks + 1) * 8);
   ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g->h_jobs), max_chunks * sizeof(Job)) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g->h_k1jobs), g->max_k1jobs * sizeof(Job)) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g->h_blocks), g->max_blocks * sizeof(BBlock)) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void **>(&g->h_total), 64) == hipSuccess;
   for (auto &e : g->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -191,7 +202,24 @@ extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, 
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
   }
+  size_t nk1 = 0;
+  for (size_t c = 0; c < nchunks; c++) {
+    const Job &J = g->h_jobs[c];
+    if ((size_t)J.len <= g->seg_bytes + g->seg_bytes / 2) {
+      g->h_k1jobs[nk1++] = J;
+      continue;
+    }
+    for (size_t p = 0; p < J.len; p += g->seg_bytes) { // segment boundaries are block boundaries
+      Job S = J;
+      S.start = (uint32_t)(p > g->d.P.max_distance ? p - g->d.P.max_distance : 0);
+      S.store_from = (uint32_t)p;
+      S.len = (uint32_t)std::min<size_t>(J.len, p + g->seg_bytes);
+      if (nk1 >= g->max_k1jobs) return fail(M4G_ERR_INTERNAL, "segment list overflow");
+      g->h_k1jobs[nk1++] = S;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(g->d_jobs, g->h_jobs, nchunks * sizeof(Job), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(g->d_k1jobs, g->h_k1jobs, nk1 * sizeof(Job), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(g->d_blocks, g->h_blocks, nb * sizeof(BBlock), hipMemcpyHostToDevice, st));
   const uint64_t src_total = chunk_off[nchunks];
   HIP_TRY(hipEventRecord(g->ev[0], st));
@@ -200,13 +228,13 @@ extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, 
   while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
   const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits));
   if (cb < 1) return fail(M4G_ERR_TOO_LARGE, "buffer positions need all 32 bits");
-  const int njobs = (int)nchunks;
+  const int njobs = (int)nk1;
   for (int t = 0; t < g->d.nt; t++) {
     const KbTable &T = g->d.P.t[t];
     const int pb = std::min((int)T.bits, kMaxPartBits), nparts = 1 << ((int)T.bits - pb);
     g->d.P.t[t].chain_base_off = (uint64_t)t * g->chain_words;
     hipLaunchKernelGGL((k1x_chain_build<false, true>), dim3((unsigned)(((njobs + 7) / 8) * 8 * nparts)), dim3(KX_THREADS),
-                       k1x_lds_bytes(pb), st, d_src, src_total, g->d_chain + (size_t)t * g->chain_words, g->d_jobs,
+                       k1x_lds_bytes(pb), st, d_src, src_total, g->d_chain + (size_t)t * g->chain_words, g->d_k1jobs,
                        (uint32_t *)nullptr, njobs, g->d.hash_len[t], (int)T.bits, pb, cb, 0, (const StreamInfo *)nullptr,
                        (uint32_t *)nullptr, T.mul_lo, T.mul_hi, bs, T.mul2, g->d.P.tail - 1);
     HIP_TRY(hipGetLastError());
@@ -285,8 +313,16 @@ extern "C" int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int
     return fail(M4G_ERR_NO_MEMORY, "device allocation failed (m4g_bargain_find_blocks)");
   }
   const uint64_t chunk_off[2] = {0, n};
+  static const bool timing = std::getenv("M4G_V2_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   if (hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) r = fail(M4G_ERR_HIP, "upload failed");
+  const auto t1 = std::chrono::steady_clock::now();
   if (r == M4G_OK) r = m4g_bargain_run_device(g, d_src, chunk_off, 1, d_out, cap, d_off, nullptr);
+  if (timing)
+    std::fprintf(stderr, "m4g_bargain_find_blocks: upload %.1f ms, run %.1f ms (links %.1f costs %.1f search %.1f compact %.1f)\n",
+                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), g->ms[0], g->ms[1],
+                 g->ms[2], g->ms[3]);
   if (r >= 0) {
     if ((uint64_t)r > out_cap) {
       r = -(int64_t)((uint64_t)r + M4G_STREAM_NEEDED_BIAS);
@@ -313,11 +349,51 @@ extern "C" int64_t m4g_brotli_compress_v2(int level, int device, const uint8_t *
   p.skip = level == 7 ? 1 : 0;
   p.block_size = 1 << 16;
   const size_t bs = (size_t)p.block_size, nb = (n + bs - 1) / bs;
-  std::vector<m4g_match> matches(n / 3 + 2 * nb + 8);
+  static const bool timing = std::getenv("M4G_V2_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n == 0) { // Close() alone: one empty last block
+    const uint64_t off0[1] = {0};
+    return m4g_brotli_encode_blocks(device, src, 0, bs, nullptr, off0, out, out_cap);
+  }
+  if (n >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "m4g_brotli_compress_v2: at most 2 GiB per call");
+  // the bytes go up once; the Match lists stay on the device between the finder and the encoder
+  struct Dev {
+    m4g_bargain *g = nullptr;
+    uint8_t *src = nullptr;
+    m4g_match *m = nullptr;
+    uint64_t *off = nullptr;
+    ~Dev() {
+      (void)hipFree(src);
+      (void)hipFree(m);
+      (void)hipFree(off);
+      m4g_bargain_destroy(g);
+    }
+  } D;
+  if (int rc = m4g_bargain_create(&p, device, 1, n, n, &D.g)) return rc;
+  const size_t mcap = n / 3 + 2 * nb + 8;
+  if (hipMalloc(reinterpret_cast<void **>(&D.src), n + 64) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&D.m), mcap * sizeof(m4g_match)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&D.off), (nb + 1) * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(M4G_ERR_NO_MEMORY, "device allocation failed (m4g_brotli_compress_v2)");
+  }
+  HIP_TRY(hipMemcpy(D.src, src, n, hipMemcpyHostToDevice));
+  const uint64_t chunk_off[2] = {0, n};
+  const int64_t nm = m4g_bargain_run_device(D.g, D.src, chunk_off, 1, D.m, mcap, D.off, nullptr);
+  if (nm < 0) return nm < -(int64_t)M4G_STREAM_NEEDED_BIAS ? fail(M4G_ERR_INTERNAL, "Match list larger than its bound") : nm;
   std::vector<uint64_t> off(nb + 1, 0);
-  const int64_t nm = m4g_bargain_find_blocks(&p, device, src, n, matches.data(), matches.size(), off.data());
-  if (nm < 0) return nm;
-  return m4g_brotli_encode_blocks(device, src, n, bs, matches.data(), off.data(), out, out_cap);
+  HIP_TRY(hipMemcpy(off.data(), D.off, (nb + 1) * 8, hipMemcpyDeviceToHost));
+  const auto t1 = std::chrono::steady_clock::now();
+  BlockUpload U;
+  if (int rc = U.init(device, nullptr, n, bs, nullptr, off.data(), true, D.src, D.m)) return rc;
+  const int64_t r = brotli_encode_uploaded(U, nullptr, n, out, out_cap, "m4g_brotli_compress_v2");
+  if (timing) {
+    const auto t2 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "m4g_brotli_compress_v2: set-up + upload + finder %.1f ms (links %.1f costs %.1f search %.1f compact %.1f), "
+                 "encoder %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), D.g->ms[0], D.g->ms[1], D.g->ms[2],
+                 D.g->ms[3], std::chrono::duration<double, std::milli>(t2 - t1).count());
+  }
+  return r;
 }
 
 #ifdef KB_STATS

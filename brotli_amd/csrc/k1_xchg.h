@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void kx_order_selftest(uint32_t *__restrict__ 
 // ((u & mask) * (prime << s)) >> (64 - bits) -- and every job is a stream cut into
 // blocks of `batch_block` bytes (>= KX_SUB + 11) whose last xtail (7, or 11 for
 // Bargain3) positions are not inserted (bargain1.go:136-139, bargain3.go:153),
-// as in the STREAM form.  xmul2 != 0: Bargain3's 12-byte hash
+// as in the STREAM form; a job may be a SEGMENT of a long stream that first inserts the
+// positions [start, store_from) without chain entries (table priming).  xmul2 != 0: Bargain3's 12-byte hash
 // (u * mul + uint64(e) * (xmul2 << 32), bargain3.go:276-278; e = the 4 bytes at i + 8).
 template <bool STREAM, bool XH = false>
 __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
   const uint32_t st_x0 = STREAM ? si->x0 : 0u, st_xend = STREAM ? si->x_end : 0xFFFFFFFFu;
   const uint32_t st_block = STREAM ? si->block_size : 0u, st_nbp = STREAM ? si->nbp : 1u;
   uint32_t bpi = 0; // breakpoint in force at the current tile
-  const uint32_t store_from = STREAM ? J.store_from : 0u;
+  const uint32_t store_from = (STREAM || XH) ? J.store_from : 0u;
 
   // hash = ((v & mask) * kHashMul64) >> (64 - table_bits), in 32-bit pieces
   const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(KX_THREADS) void k1x_chain_build(
         uint32_t *cp = chain + (sb - 2 * KX_SUB); // wave-uniform
 #pragma unroll
         for (int j = 0; j < KX_PER; j++)
-          if ((in2 >> j & 1) && (!STREAM || sb - 2 * KX_SUB + my_rel + j * 64 >= store_from))
+          if ((in2 >> j & 1) && (!(STREAM || XH) || sb - 2 * KX_SUB + my_rel + j * 64 >= store_from))
             cp[my_rel + j * 64] = ce[j];
       }
       if (lane == 0) cnt[par * 16 + wave] = total;

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -835,9 +836,10 @@ struct BlockUpload {
   std::vector<Job> jobs;
   std::vector<uint64_t> lens, off;
   uint64_t nmatches = 0;
+  bool borrowed = false; // d_src / d_m belong to the caller (bytes and Match lists already on the device)
   ~BlockUpload() {
-    (void)hipFree(d_src);
-    (void)hipFree(d_m);
+    if (!borrowed) (void)hipFree(d_src);
+    if (!borrowed) (void)hipFree(d_m);
     (void)hipFree(d_off);
     (void)hipFree(d_jobs);
     if (e0) (void)hipEventDestroy(e0);
@@ -846,9 +848,11 @@ struct BlockUpload {
   }
   // whole_stream: jobs = every full block + the remainder, possibly empty (Write; Close).  Otherwise exactly the
   // ceil(n / block_size) blocks of the lists.
+  // dev_src / dev_matches non-null: the bytes and the Match lists are on the device already (src, matches unused)
   int init(int device, const uint8_t *src, size_t n, size_t block_size, const m4g_match *matches, const uint64_t *block_off,
-           bool whole_stream = true) {
-    if ((!src && n) || block_size == 0 || !block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
+           bool whole_stream = true, uint8_t *dev_src = nullptr, m4g_match *dev_matches = nullptr) {
+    borrowed = dev_src != nullptr;
+    if ((!src && n && !borrowed) || block_size == 0 || !block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
     if (n >= ((uint64_t)1 << 32)) return fail(M4G_ERR_TOO_LARGE, "at most 4 GiB per call");
     if (block_size >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "block_size must stay below 2^31");
     if (int rc = check_device(device)) return rc;
@@ -869,15 +873,19 @@ struct BlockUpload {
     }
     off[njobs] = block_off[nlists];
     nmatches = block_off[nlists];
-    if (nmatches && !matches) return fail(M4G_ERR_BAD_PARAM, "matches is NULL");
+    if (nmatches && !matches && !borrowed) return fail(M4G_ERR_BAD_PARAM, "matches is NULL");
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    if (hipMalloc(&d_src, n + 64) != hipSuccess || hipMalloc(&d_m, (nmatches + 1) * sizeof(m4g_match)) != hipSuccess ||
-        hipMalloc(&d_off, (njobs + 1) * 8) != hipSuccess || hipMalloc(&d_jobs, njobs * sizeof(Job)) != hipSuccess)
+    if (borrowed) {
+      d_src = dev_src, d_m = dev_matches;
+    } else if (hipMalloc(&d_src, n + 64) != hipSuccess || hipMalloc(&d_m, (nmatches + 1) * sizeof(m4g_match)) != hipSuccess) {
       return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
-    if (n) HIP_TRY(hipMemcpyAsync(d_src, src, n, hipMemcpyHostToDevice, st));
-    if (nmatches) HIP_TRY(hipMemcpyAsync(d_m, matches, nmatches * sizeof(m4g_match), hipMemcpyHostToDevice, st));
+    }
+    if (hipMalloc(&d_off, (njobs + 1) * 8) != hipSuccess || hipMalloc(&d_jobs, njobs * sizeof(Job)) != hipSuccess)
+      return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
+    if (n && !borrowed) HIP_TRY(hipMemcpyAsync(d_src, src, n, hipMemcpyHostToDevice, st));
+    if (nmatches && !borrowed) HIP_TRY(hipMemcpyAsync(d_m, matches, nmatches * sizeof(m4g_match), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_off, off.data(), (njobs + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), njobs * sizeof(Job), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st)); // (the host buffers above may be pageable)
@@ -902,22 +910,23 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
 
 // matchfinder.Writer{MatchFinder: M4, Encoder: &brotli.Encoder{}, BlockSize} over one whole input, given the Match
 // lists of its blocks (m4g_find_matches_blocks): include/m4g.h.
-extern "C" int64_t m4g_brotli_encode_blocks(int device, const uint8_t *src, size_t n, size_t block_size,
-                                            const m4g_match *matches, const uint64_t *block_off, uint8_t *stream_out,
-                                            size_t stream_cap) {
-  BlockUpload U;
-  if (int rc = U.init(device, src, n, block_size, matches, block_off)) return rc;
+namespace {
+// Both passes of Encoder.Encode over the blocks of U.  matches: the host copy of the Match lists, or NULL when they
+// exist on the device only (then the long literal runs are listed by a kernel).
+int64_t brotli_encode_uploaded(BlockUpload &U, const m4g_match *matches, size_t n, uint8_t *stream_out, size_t stream_cap,
+                               const char *what) {
   const size_t njobs = U.jobs.size();
   // pass 1 of Encoder.Encode for every block (K5); literal runs of K5_HUGE bytes or more go to the side kernel,
-  // whose list K4 builds in the batch pipeline and the host builds here
+  // whose list K4 builds in the batch pipeline and the host (or kb_long_runs) builds here
   std::vector<LongRun> runs;
   uint32_t max_len = 0;
   for (size_t j = 0; j < njobs; j++) {
     uint32_t pos = 0;
     max_len = std::max(max_len, U.jobs[j].len);
+    if (!matches) continue;
     for (uint64_t k = U.off[j]; k < U.off[j + 1]; k++) {
       if (matches[k].length == 1) // no copy length code for 1 (command.go:128); M4 never returns it with MinLength >= 2
-        return fail(M4G_ERR_BAD_PARAM, "m4g_brotli_encode_blocks: a match of Length 1");
+        return fail(M4G_ERR_BAD_PARAM, std::string(what) + ": a match of Length 1");
       if (matches[k].unmatched >= K5_HUGE) runs.push_back(LongRun{(uint32_t)j, pos, matches[k].unmatched, 0});
       pos += matches[k].unmatched + matches[k].length;
     }
@@ -936,26 +945,41 @@ extern "C" int64_t m4g_brotli_encode_blocks(int device, const uint8_t *src, size
       B.release();
     }
   } D;
+  const uint32_t run_cap = matches ? (uint32_t)runs.size() : (uint32_t)(n / K5_HUGE + njobs + 1);
   const uint32_t nruns = (uint32_t)runs.size();
   if (hipMalloc(&D.histos, njobs * sizeof(m4g_histo)) != hipSuccess ||
       hipMalloc(&D.codes, (U.nmatches + 1) * sizeof(CodeRec)) != hipSuccess ||
-      hipMalloc(&D.runs, (runs.size() + 1) * sizeof(LongRun)) != hipSuccess || hipMalloc(&D.nruns, 4) != hipSuccess)
+      hipMalloc(&D.runs, ((size_t)run_cap + 1) * sizeof(LongRun)) != hipSuccess || hipMalloc(&D.nruns, 4) != hipSuccess)
     return fail(M4G_ERR_NO_MEMORY, "hipMalloc failed");
   if (nruns) HIP_TRY(hipMemcpyAsync(D.runs, runs.data(), runs.size() * sizeof(LongRun), hipMemcpyHostToDevice, U.st));
   HIP_TRY(hipMemcpyAsync(D.nruns, &nruns, 4, hipMemcpyHostToDevice, U.st));
+  if (!matches && U.nmatches) {
+    hipLaunchKernelGGL(kb_long_runs, dim3((unsigned)((njobs + 63) / 64)), dim3(64), 0, U.st, U.d_m, U.d_off, (uint32_t)njobs,
+                       D.runs, D.nruns, run_cap);
+    HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, U.st, U.d_src,
                      reinterpret_cast<const uint32_t *>(U.d_m), U.d_jobs, U.d_off, (uint64_t)U.nmatches, D.histos, D.codes);
   HIP_TRY(hipGetLastError());
   const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
-  if (nruns) {
+  if (run_cap) {
     hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, U.st, U.d_src, U.d_jobs, D.runs, D.nruns,
-                       nruns, segs, U.d_off, (uint64_t)U.nmatches, D.histos);
+                       run_cap, segs, U.d_off, (uint64_t)U.nmatches, D.histos);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(U.st)); // (`nruns` and `runs` are stack / pageable)
   return brotli_encode_jobs(D.B, U.e0, U.e1, U.d_src, U.d_jobs, U.lens, U.d_m, U.d_off,
                             reinterpret_cast<const m4g_histo *>(D.histos), reinterpret_cast<const m4g_code *>(D.codes), 3,
-                            stream_out, stream_cap, U.st, nullptr, "m4g_brotli_encode_blocks");
+                            stream_out, stream_cap, U.st, nullptr, what);
+}
+} // namespace
+
+extern "C" int64_t m4g_brotli_encode_blocks(int device, const uint8_t *src, size_t n, size_t block_size,
+                                            const m4g_match *matches, const uint64_t *block_off, uint8_t *stream_out,
+                                            size_t stream_cap) {
+  BlockUpload U;
+  if (int rc = U.init(device, src, n, block_size, matches, block_off)) return rc;
+  return brotli_encode_uploaded(U, matches, n, stream_out, stream_cap, "m4g_brotli_encode_blocks");
 }
 
 // ===========================================================================

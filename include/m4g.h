@@ -483,8 +483,8 @@ int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int device, co
 
 /* Replaces: w := brotli.NewWriterV2(dst, level); w.Write(src); w.Close() for levels 5-9 (writer.go:126-161:
  * matchfinder.Writer{MatchFinder: Bargain1 | Bargain2{Skip} | Bargain2 | Bargain3, MaxDistance 1 << 20,
- * Encoder: &Encoder{}, BlockSize: 1 << 16}) -- m4g_bargain_find_blocks, then m4g_brotli_encode_blocks.
- * Host memory in, the complete brotli stream out.  Levels above 9 mean 9 (writer.go:129-131); levels 0-4 use
+ * Encoder: &Encoder{}, BlockSize: 1 << 16}): the bytes go to the device once, the Match lists never leave it.
+ * Host memory in (at most 2 GiB), the complete brotli stream out.  Levels above 9 mean 9 (writer.go:129-131); levels 0-4 use
  * other match finders (ZFast, ZDFast, ZM, Trio), which are not built: M4G_ERR_BAD_PARAM.  Returns the stream
  * length, -(needed + M4G_STREAM_NEEDED_BIAS) when out_cap is too small, or an M4G_ERR_*. */
 int64_t m4g_brotli_compress_v2(int level, int device, const uint8_t *src, size_t n, uint8_t *out,

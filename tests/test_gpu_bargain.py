@@ -48,6 +48,14 @@ def test_kinds(variant):
     same(text(600000, 14), variant, bs=1 << 18)                                   # blocks longer than the Writer's default
 
 
+@pytest.mark.parametrize("variant,md", [(1, 1 << 20), (2, 1 << 16), (3, 1 << 20)])
+def test_long_stream_is_segmented(variant, md):
+    """A stream longer than 6 MiB is cut into 4 MiB segments for K1, each primed with the MaxDistance bytes before it;
+    the second half repeats the first beyond MaxDistance (predecessors that exist but must be rejected)."""
+    a = text(4_700_000, 30 + variant)
+    same(a + a[:4_300_001], variant, md=md)
+
+
 def test_tiny_and_edges():
     for n in (1, 7, 8, 9, 11, 12, 13, 63, 64, 65, 4095, 4096, 4097):
         for variant in (1, 3):

@@ -51,7 +51,7 @@ bl, bd = last_json(os.path.join(run, "bench_log.json")), last_json(os.path.join(
 for name, d in ((f"{tag}_bench.json", b), (f"{tag}_bench_log.json", bl), (f"{tag}_bench_D.json", bd)):
     json.dump(d, open(P(name), "w"))
 for f in ("kind_probe.log", "stream_probe.log", "hostbatch_probe.log", "writer_probe.log", "compress_probe.log",
-          "bargain_probe.log", "bargain_stats.log"):
+          "bargain_probe.log", "bargain_stats.log", "v2_probe.log"):
     if os.path.exists(os.path.join(run, f)):
         shutil.copy(os.path.join(run, f), P(f"{tag}_{f}"))
 for key, fd, wd in (("text/G", "pmc_fetch", "pmc_write"), ("text/D", "pmc_fetch_D", "pmc_write_D"),
@@ -138,7 +138,8 @@ gb = b.get("gpu_bargain", {})
 L.append(f"Bargain1 (NewWriterV2 levels 5-6; {gb.get('chunks')} streams of 1 MiB in 64 KiB blocks = {gb.get('blocks')} blocks, one wavefront "
          f"each): {gb.get('value')} GB/s ({gb.get('ms')} ms: {gb.get('stage_ms')}), {gb.get('bytes_per_match')} bytes per Match, first "
          f"{gb.get('chunks_compared')} streams equal the restated finder: {gb.get('first_chunks_equal_restated_finder')}; the restated finder "
-         f"on one core {gb.get('cpu_restated_MB_s_one_core')} MB/s; Bargain2 / Bargain3 and other sizes: `profiles/{tag}_bargain_probe.log`.\n")
+         f"on one core {gb.get('cpu_restated_MB_s_one_core')} MB/s; Bargain2 / Bargain3 and other sizes: `profiles/{tag}_bargain_probe.log`; NewWriterV2(dst, 5..9) end to end on one 256 MiB stream "
+         f"(m4g_brotli_compress_v2): `profiles/{tag}_v2_probe.log`.\n")
 L.append("Other workloads (1024 x 1 MiB chunks, same run):\n")
 L.append(f"* low-entropy binary log, params G (BASELINE config 5): {bl['value']} GB/s, stage_ms {bl['stage_ms']}, ratio {bl['config']['compression_ratio']}, roofline.traffic {bl['roofline']['traffic']} GB")
 L.append(f"* text, params D (ChainLength 64, HashLen 5; BASELINE config 4): {bd['value']} GB/s, stage_ms {bd['stage_ms']}, ratio {bd['config']['compression_ratio']}, roofline.traffic {bd['roofline']['traffic']} GB")

@@ -33,5 +33,6 @@ step hostb   bash -c "timeout -k 10 200 python tools/hostbatch_probe.py 2048 > $
 step writer  bash -c "timeout -k 10 200 python tools/writer_probe.py 256 > $out/writer_probe.log 2>&1"
 step bargain bash -c "(for a in '64 1' '512 1' '512 2' '512 3'; do timeout -k 10 300 python tools/bargain_probe.py \$a 1 || exit 1; done) > $out/bargain_probe.log 2>&1"
 step bstats  bash -c "timeout -k 10 400 bash tools/bargain_stats.sh > $out/bargain_stats.log 2>&1"
+step v2      bash -c "timeout -k 10 400 python tools/v2_probe.py 256 > $out/v2_probe.log 2>&1"
 step compr   bash -c "timeout -k 10 200 python tools/compress_probe.py 256 > $out/compress_probe.log 2>&1"
 tail -1 "$out/bench.json" | cut -c1-400
