@@ -229,6 +229,25 @@ def bargain_leg(host, n: int, chunks: int, dev, device_index: int, no_cpu: bool)
         res["cpu_restated_MB_s_one_core"] = round(k * n / dt / 1e6, 1)
         res["first_chunks_equal_restated_finder"] = ok
         res["chunks_compared"] = k
+    # brotli.NewWriterV2(dst, 5) + Write + Close on ONE stream, host memory to host memory (m4g_brotli_compress_v2)
+    try:
+        nbytes = min(chunks * n, 256 << 20)
+        m4.brotli_compress_v2(host[:1 << 20], 5)
+        best, stream = None, b""
+        for _ in range(2):
+            t0 = time.perf_counter()
+            stream = m4.brotli_compress_v2(host[:nbytes], 5)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        v2 = {"value": round(nbytes / best / 1e9, 3), "unit": "GB/s", "ms": round(best * 1e3, 1), "stream_bytes_in": nbytes,
+              "compression_ratio": round(nbytes / max(len(stream), 1), 4),
+              "sample": "one stream, pageable host memory in and out, plan creation and every allocation inside the call"}
+        if not no_cpu:
+            from oracle_lib import brotli_decompress
+            v2["decodes_to_input"] = brotli_decompress(stream, nbytes) == host[:nbytes].tobytes()
+        res["new_writer_v2_level5"] = v2
+    except m4.M4GError as e:
+        res["new_writer_v2_level5"] = {"error": str(e)}
     return res
 
 

@@ -169,9 +169,21 @@ extern "C" size_t m4g_bargain_block_count(const m4g_bargain *g, const uint64_t *
   return nb;
 }
 
+namespace {
+int64_t bargain_run_impl(m4g_bargain *g, const uint8_t *d_src, const uint64_t *chunk_off, size_t nchunks, m4g_match *d_out,
+                         size_t out_cap, uint64_t *d_block_off, void *hip_stream, uint32_t first_pos);
+}
 extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, const uint64_t *chunk_off, size_t nchunks,
                                           m4g_match *d_out, size_t out_cap, uint64_t *d_block_off, void *hip_stream) {
+  return bargain_run_impl(g, d_src, chunk_off, nchunks, d_out, out_cap, d_block_off, hip_stream, 0);
+}
+namespace {
+// first_pos (one chunk only, a multiple of block_size): the chunk's first first_pos bytes are history of earlier
+// calls -- inserted into the tables, not searched; the blocks start there.
+int64_t bargain_run_impl(m4g_bargain *g, const uint8_t *d_src, const uint64_t *chunk_off, size_t nchunks, m4g_match *d_out,
+                         size_t out_cap, uint64_t *d_block_off, void *hip_stream, uint32_t first_pos) {
   if (!g || !d_src || !chunk_off || (!d_out && out_cap) || !d_block_off) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (first_pos && (nchunks != 1 || first_pos % g->d.P.block_size)) return fail(M4G_ERR_INTERNAL, "first_pos");
   if (nchunks > g->max_chunks) return fail(M4G_ERR_TOO_LARGE, "more chunks than the plan holds");
   HIP_TRY(hipSetDevice(g->device));
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -190,7 +202,7 @@ extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, 
   for (size_t c = 0; c < nchunks; c++) {
     const uint32_t n = g->h_jobs[c].len;
     max_len = std::max(max_len, n);
-    for (uint32_t p = 0; p < n; p += bs) {
+    for (uint32_t p = first_pos; p < n; p += bs) {
       BBlock B{};
       B.job = (uint32_t)c, B.start = p, B.len = std::min(bs, n - p);
       g->h_blocks[nb++] = B;
@@ -205,11 +217,13 @@ extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, 
   size_t nk1 = 0;
   for (size_t c = 0; c < nchunks; c++) {
     const Job &J = g->h_jobs[c];
-    if ((size_t)J.len <= g->seg_bytes + g->seg_bytes / 2) {
-      g->h_k1jobs[nk1++] = J;
+    if ((size_t)J.len - first_pos <= g->seg_bytes + g->seg_bytes / 2) {
+      Job S = J;
+      S.store_from = first_pos;
+      g->h_k1jobs[nk1++] = S;
       continue;
     }
-    for (size_t p = 0; p < J.len; p += g->seg_bytes) { // segment boundaries are block boundaries
+    for (size_t p = first_pos; p < J.len; p += g->seg_bytes) { // segment boundaries are block boundaries
       Job S = J;
       S.start = (uint32_t)(p > g->d.P.max_distance ? p - g->d.P.max_distance : 0);
       S.store_from = (uint32_t)p;
@@ -272,6 +286,7 @@ extern "C" int64_t m4g_bargain_run_device(m4g_bargain *g, const uint8_t *d_src, 
   if (nm > out_cap) return -(int64_t)(nm + M4G_STREAM_NEEDED_BIAS);
   return (int64_t)nm;
 }
+} // namespace
 
 extern "C" int m4g_bargain_last_timings(const m4g_bargain *g, float *ms, int cap) {
   if (!g || !ms) return 0;
@@ -394,6 +409,120 @@ extern "C" int64_t m4g_brotli_compress_v2(int level, int device, const uint8_t *
                  D.g->ms[3], std::chrono::duration<double, std::milli>(t2 - t1).count());
   }
   return r;
+}
+
+// ---- matchfinder.Writer with a Bargain finder: brotli.NewWriterV2(dst, 5..9) as a streaming handle -------------
+namespace {
+template <class T> int grow_dev(T **p, size_t *cap, size_t need) {
+  if (need <= *cap) return M4G_OK;
+  (void)hipFree(*p);
+  *p = nullptr, *cap = 0;
+  const size_t want = need + need / 2 + 64;
+  if (hipMalloc(reinterpret_cast<void **>(p), want * sizeof(T)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(M4G_ERR_NO_MEMORY, "device allocation failed (m4g_writer, Bargain)");
+  }
+  *cap = want;
+  return M4G_OK;
+}
+
+// The blocks of `span` (whole blocks of bs bytes; final: Close()'s remainder, shorter than a block, possibly empty).
+// The finder sees the stream so far through the bytes kept in w->bhist: whole blocks, at least MaxDistance of them once
+// the stream is that long -- a table entry further back is rejected by bargain1.go:166 whether it survives the
+// reference's slides (bargain1.go:66-80) or not, and the blocks keep their alignment, so K1's rule for the last
+// positions of a block (bargain1.go:136) and Skip's parity (bargain1.go:159; block sizes are even) see what the
+// reference sees.
+int writer_process_bargain(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bool final) {
+  HIP_TRY(hipSetDevice(w->device));
+  if (bs == 0 || (!final && len % bs) || (final && len >= bs)) return fail(M4G_ERR_INTERNAL, "m4g_writer (Bargain): block structure");
+  const size_t hist = w->bhist.size(), total = hist + len;
+  const size_t nlists = (len + bs - 1) / bs;              // blocks the finder sees
+  const size_t njobs = final ? std::max<size_t>(nlists, 1) : nlists; // blocks the encoder sees (Close: one, possibly empty)
+  if (njobs == 0) return M4G_OK;
+  if (total >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "at most 2 GiB of history + data per Write");
+  w->bchunk.resize(total);
+  if (hist) std::memcpy(w->bchunk.data(), w->bhist.data(), hist);
+  if (len) std::memcpy(w->bchunk.data() + hist, span, len);
+  if (int rc = grow_dev(&w->d_bsrc, &w->d_bsrc_cap, total + 64)) return rc;
+  if (int rc = grow_dev(&w->d_bm, &w->d_bm_cap, len / 3 + 2 * nlists + 8)) return rc;
+  if (int rc = grow_dev(&w->d_boff, &w->d_boff_cap, njobs + 2)) return rc;
+  if (int rc = grow_dev(&w->d_bjobs, &w->d_bjobs_cap, njobs + 1)) return rc;
+  if (total) HIP_TRY(hipMemcpy(w->d_bsrc, w->bchunk.data(), total, hipMemcpyHostToDevice));
+  uint64_t nm = 0;
+  std::vector<uint64_t> off(njobs + 1, 0);
+  if (nlists) {
+    if (!w->bplan || total > w->bplan_bytes) {
+      m4g_bargain_destroy(w->bplan);
+      w->bplan = nullptr;
+      const size_t cap = std::max<size_t>(total + total / 2, (size_t)8 << 20);
+      if (int rc = m4g_bargain_create(&w->bp, w->device, 1, cap, cap, &w->bplan)) return rc;
+      w->bplan_bytes = cap;
+    }
+    const uint64_t chunk_off[2] = {0, total};
+    const int64_t r = bargain_run_impl(w->bplan, w->d_bsrc, chunk_off, 1, w->d_bm, w->d_bm_cap, w->d_boff, nullptr, (uint32_t)hist);
+    if (r < 0) return r < -(int64_t)M4G_STREAM_NEEDED_BIAS ? fail(M4G_ERR_INTERNAL, "Match list larger than its bound") : (int)r;
+    nm = (uint64_t)r;
+    HIP_TRY(hipMemcpy(off.data(), w->d_boff, (nlists + 1) * 8, hipMemcpyDeviceToHost));
+  } else {
+    HIP_TRY(hipMemcpy(w->d_boff, off.data(), (njobs + 1) * 8, hipMemcpyHostToDevice));
+  }
+  // the encoder's jobs: block k = bytes [hist + k * bs, ...) of the device copy
+  std::vector<Job> jobs(njobs);
+  std::vector<uint64_t> lens(njobs);
+  for (size_t k = 0; k < njobs; k++) {
+    Job J{};
+    J.src_off = hist + k * bs;
+    J.len = (uint32_t)std::min<size_t>(bs, total - J.src_off);
+    jobs[k] = J;
+    lens[k] = J.len;
+  }
+  HIP_TRY(hipMemcpy(w->d_bjobs, jobs.data(), njobs * sizeof(Job), hipMemcpyHostToDevice));
+  const size_t run_cap = len / K5_HUGE + njobs + 64;
+  if (int rc = writer_reserve_brotli(w, njobs, nm, run_cap)) return rc;
+  HIP_TRY(hipMemsetAsync(w->d_nruns, 0, 4, nullptr));
+  if (nm) {
+    hipLaunchKernelGGL(kb_long_runs, dim3((unsigned)((njobs + 63) / 64)), dim3(64), 0, nullptr, w->d_bm, w->d_boff, (uint32_t)njobs,
+                       w->d_runs, w->d_nruns, (uint32_t)(w->runs_cap - 1));
+    HIP_TRY(hipGetLastError());
+  }
+  if (int rc = writer_encode(w, w->d_bsrc, w->d_bjobs, lens, w->d_bm, w->d_boff, nm, nullptr, final)) return rc;
+  // what the next call needs of the stream: its last whole blocks, MaxDistance bytes or more
+  const size_t md = w->bp.max_distance ? (size_t)w->bp.max_distance : (size_t)1 << 16;
+  const size_t keep = (md + bs - 1) / bs * bs;
+  if (!final) {
+    if (total > keep) w->bhist.assign(w->bchunk.begin() + (total - keep), w->bchunk.end());
+    else w->bhist = w->bchunk;
+  }
+  return M4G_OK;
+}
+} // namespace
+
+// w := brotli.NewWriterV2(dst, level) for levels 5-9 (writer.go:126-161) as an m4g_writer: m4g_writer_write /
+// _close / _reset / _destroy are its Write / Close / Reset.
+extern "C" int m4g_writer_create_v2(int level, int device, m4g_writer **out) {
+  if (!out) return fail(M4G_ERR_BAD_PARAM, "out is NULL");
+  *out = nullptr;
+  if (level > 9) level = 9; // writer.go:129-131
+  if (level < 5)
+    return fail(M4G_ERR_BAD_PARAM, "NewWriterV2 levels 0-4 use ZFast / ZDFast / ZM / Trio, which are not built (levels 5-9 are)");
+  if (int rc = check_device(device)) return rc;
+  HIP_TRY(hipSetDevice(device));
+  m4g_writer *w = new (std::nothrow) m4g_writer();
+  if (!w) return fail(M4G_ERR_NO_MEMORY, "host allocation failed");
+  w->v2 = true;
+  w->bp.variant = level <= 6 ? 1 : (level <= 8 ? 2 : 3);
+  w->bp.max_distance = 1 << 20;
+  w->bp.skip = level == 7 ? 1 : 0;
+  w->bp.block_size = 1 << 16;
+  w->device = device;
+  w->format = M4G_FORMAT_BROTLI;
+  w->bs = (size_t)1 << 16;
+  if (hipEventCreate(&w->e0) != hipSuccess || hipEventCreate(&w->e1) != hipSuccess) {
+    m4g_writer_destroy(w);
+    return fail(M4G_ERR_HIP, "hipEventCreate failed");
+  }
+  *out = w;
+  return M4G_OK;
 }
 
 #ifdef KB_STATS

@@ -2710,6 +2710,18 @@ struct m4g_writer {
   std::vector<uint8_t> stage;
   bool closed_pending = false; // Close() has encoded the last block; its bytes wait for a large enough `out`
   bool failed = false;         // a call failed half way: the handle's state is undefined until m4g_writer_reset
+  // MatchFinder = Bargain1 / 2 / 3 instead of M4 (m4g_writer_create_v2; bargain_host.h): ctx stays NULL
+  bool v2 = false;
+  m4g_bargain_params bp{};
+  m4g_bargain *bplan = nullptr;
+  size_t bplan_bytes = 0;       // what the plan holds
+  std::vector<uint8_t> bhist;   // the stream's last bytes: whole blocks, at least MaxDistance bytes once it is that long
+  std::vector<uint8_t> bchunk;  // bhist + the call's blocks, contiguous (what goes to the device)
+  uint8_t *d_bsrc = nullptr;
+  m4g_match *d_bm = nullptr;
+  uint64_t *d_boff = nullptr;
+  Job *d_bjobs = nullptr;
+  size_t d_bsrc_cap = 0, d_bm_cap = 0, d_boff_cap = 0, d_bjobs_cap = 0;
 };
 
 namespace {
@@ -2784,7 +2796,9 @@ int writer_process(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bo
   if (rc) w->failed = true;
   return rc;
 }
+int writer_process_bargain(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bool final); // bargain_host.h
 int writer_process_impl(m4g_writer *w, const uint8_t *span, size_t len, size_t bs, bool final) {
+  if (w->v2) return writer_process_bargain(w, span, len, bs, final);
   m4g_ctx *c = w->ctx;
   const Params &p = c->p;
   HIP_TRY(hipSetDevice(w->device));
@@ -2890,6 +2904,11 @@ extern "C" void m4g_writer_destroy(m4g_writer *w) {
   if (w->e0) (void)hipEventDestroy(w->e0);
   if (w->e1) (void)hipEventDestroy(w->e1);
   m4g_destroy(w->ctx);
+  m4g_bargain_destroy(w->bplan);
+  (void)hipFree(w->d_bsrc);
+  (void)hipFree(w->d_bm);
+  (void)hipFree(w->d_boff);
+  (void)hipFree(w->d_bjobs);
   delete w;
 }
 
@@ -2903,7 +2922,8 @@ extern "C" int m4g_writer_reset(m4g_writer *w) {
   w->carry = GzipCarry();
   w->closed_pending = false;
   w->failed = false;
-  return m4g_reset(w->ctx);
+  w->bhist.clear();
+  return w->v2 ? M4G_OK : m4g_reset(w->ctx);
 }
 
 extern "C" int64_t m4g_writer_write(m4g_writer *w, const uint8_t *src, size_t n, uint8_t *out, size_t out_cap) {

@@ -48,7 +48,7 @@ EXPORTS = [
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
     "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
     "m4g_bargain_create", "m4g_bargain_destroy", "m4g_bargain_block_count", "m4g_bargain_run_device",
-    "m4g_bargain_last_timings", "m4g_bargain_find_blocks", "m4g_brotli_compress_v2",
+    "m4g_bargain_last_timings", "m4g_bargain_find_blocks", "m4g_brotli_compress_v2", "m4g_writer_create_v2",
 ]
 
 _LIB = None
@@ -144,6 +144,7 @@ def lib():
         L.m4g_bargain_last_timings.argtypes = [vp, vp, ctypes.c_int]
         L.m4g_bargain_find_blocks.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, vp, sz, vp, sz, vp]
         L.m4g_bargain_find_blocks.restype = ctypes.c_int64
+        L.m4g_writer_create_v2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
         L.m4g_brotli_compress_v2.argtypes = [ctypes.c_int, ctypes.c_int, vp, sz, vp, sz]
         L.m4g_brotli_compress_v2.restype = ctypes.c_int64
         L.m4g_host_alloc.argtypes = [sz]
@@ -578,6 +579,20 @@ class GPUWriter:
         if getattr(self, "_h", None):
             lib().m4g_writer_destroy(self._h)
             self._h = None
+
+
+class NewWriterV2(GPUWriter):
+    """``brotli.NewWriterV2(dst, level)`` for levels 5-9 (writer.go:126-161): the matchfinder.Writer with Bargain1 /
+    Bargain2 / Bargain3 and brotli.Encoder, both on the GPU (m4g_writer_create_v2).  Write / Close / Reset as in the
+    reference; same bytes after the same calls."""
+
+    def __init__(self, Dest, level: int, device: int = 0):
+        self.Dest = Dest
+        self.BlockSize = 1 << 16
+        h = ctypes.c_void_p()
+        _check(lib().m4g_writer_create_v2(level, device, ctypes.byref(h)), "m4g_writer_create_v2")
+        self._h = h
+        self._buf = np.zeros(1 << 20, dtype=np.uint8)
 
 
 def brotli_compress(data, block_size: int = 1 << 16, device: int = 0, **m4_fields) -> bytes:

@@ -481,6 +481,14 @@ int m4g_bargain_last_timings(const m4g_bargain *g, float *ms, int cap);
 int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int device, const uint8_t *src,
                                 size_t n, m4g_match *out, size_t out_cap, uint64_t *block_off);
 
+/* Replaces: brotli.NewWriterV2(dst, level) for levels 5-9 (writer.go:126-161) as a streaming handle: the returned
+ * m4g_writer's m4g_writer_write / _close / _reset / _destroy are the Write / Close / Reset of the
+ * matchfinder.Writer{Bargain1 | Bargain2{Skip} | Bargain2 | Bargain3, &Encoder{}, BlockSize 1 << 16} the reference
+ * builds, with the same bytes after the same calls.  A Write that completes many blocks does them in one launch
+ * (one wavefront per block); the handle keeps the last MaxDistance bytes of the stream (whole blocks) for the next
+ * call.  Levels above 9 mean 9; levels 0-4 are M4G_ERR_BAD_PARAM (other match finders, not built). */
+int m4g_writer_create_v2(int level, int device, m4g_writer **out);
+
 /* Replaces: w := brotli.NewWriterV2(dst, level); w.Write(src); w.Close() for levels 5-9 (writer.go:126-161:
  * matchfinder.Writer{MatchFinder: Bargain1 | Bargain2{Skip} | Bargain2 | Bargain3, MaxDistance 1 << 20,
  * Encoder: &Encoder{}, BlockSize: 1 << 16}): the bytes go to the device once, the Match lists never leave it.

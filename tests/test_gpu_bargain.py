@@ -145,3 +145,51 @@ def test_new_writer_v2_levels_on_gpu(level):
         m4.brotli_compress_v2(data[:1000], 4)   # ZFast .. Trio are not built
     if level == 9:
         assert m4.brotli_compress_v2(data[:70000], 11) == m4.brotli_compress_v2(data[:70000], 9)  # writer.go:129-131
+
+
+class Sink:
+    def __init__(self):
+        self.parts = []
+
+    def write(self, b):
+        self.parts.append(bytes(b))
+
+    def value(self):
+        return b"".join(self.parts)
+
+
+@pytest.mark.parametrize("level", [5, 7, 9])
+def test_new_writer_v2_streaming_handle(level):
+    """m4g_writer_create_v2: Write in ragged pieces, Close, Reset -- the bytes the restated Writer hands to Dest,
+    whatever the sizes of the Write calls (matchfinder.go:59-103)."""
+    data = open(OPTICKS, "rb").read()
+    big = (data * 4)[:2_500_000]   # longer than MaxDistance + a few blocks: the handle's history gets cut
+    want = oracle_writer_v2(data, level)
+    dst = Sink()
+    w = m4.NewWriterV2(dst, level)
+    w.Write(data)
+    w.Close()
+    assert dst.value() == want
+    # ragged Writes, including empty ones and pieces that complete no, one and many blocks
+    dst2 = Sink()
+    w.Reset(dst2)
+    rng = np.random.default_rng(level)
+    p = 0
+    for n in [0, 1, 65535, 1, 65536, 200000, 3, 0, 131072 + 5]:
+        w.Write(data[p:p + n])
+        p += n
+    while p < len(data):
+        n = int(rng.integers(1, 150000))
+        w.Write(data[p:p + n])
+        p += n
+    w.Close()
+    assert dst2.value() == want
+    # a stream whose history is cut between calls; block-sized Writes; an exact multiple of the block size
+    for blob, step in ((big, 1 << 16), (big, 700001), (big[:32 << 16], 5 << 16), (b"", 1)):
+        dst3 = Sink()
+        w.Reset(dst3)
+        for q in range(0, len(blob), step):
+            w.Write(blob[q:q + step])
+        w.Close()
+        assert dst3.value() == oracle_writer_v2(blob, level)
+        assert brotli_decompress(dst3.value(), len(blob)) == blob

@@ -138,7 +138,8 @@ gb = b.get("gpu_bargain", {})
 L.append(f"Bargain1 (NewWriterV2 levels 5-6; {gb.get('chunks')} streams of 1 MiB in 64 KiB blocks = {gb.get('blocks')} blocks, one wavefront "
          f"each): {gb.get('value')} GB/s ({gb.get('ms')} ms: {gb.get('stage_ms')}), {gb.get('bytes_per_match')} bytes per Match, first "
          f"{gb.get('chunks_compared')} streams equal the restated finder: {gb.get('first_chunks_equal_restated_finder')}; the restated finder "
-         f"on one core {gb.get('cpu_restated_MB_s_one_core')} MB/s; Bargain2 / Bargain3 and other sizes: `profiles/{tag}_bargain_probe.log`; NewWriterV2(dst, 5..9) end to end on one 256 MiB stream "
+         f"on one core {gb.get('cpu_restated_MB_s_one_core')} MB/s; Bargain2 / Bargain3 and other sizes: `profiles/{tag}_bargain_probe.log`; NewWriterV2(dst, 5) + Write + Close on one stream, "
+         f"host to host: {gb.get('new_writer_v2_level5')}; levels 5..9 "
          f"(m4g_brotli_compress_v2): `profiles/{tag}_v2_probe.log`.\n")
 L.append("Other workloads (1024 x 1 MiB chunks, same run):\n")
 L.append(f"* low-entropy binary log, params G (BASELINE config 5): {bl['value']} GB/s, stage_ms {bl['stage_ms']}, ratio {bl['config']['compression_ratio']}, roofline.traffic {bl['roofline']['traffic']} GB")
