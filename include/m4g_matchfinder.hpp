@@ -201,6 +201,15 @@ public:
     if (rc != M4G_OK)
       throw std::runtime_error(std::string("m4g_writer_create: ") + m4g_strerror(rc) + " (" + m4g_last_error() + ")");
   }
+  // brotli.NewWriterV2(dst, level) for levels 5-9 (writer.go:126-161): Bargain1 / 2 / 3 + brotli.Encoder
+  struct V2 {
+    int level;
+  };
+  GPUWriter(Dest *d, V2 v2, int device = 0) : dest(d), buf_(1 << 20) {
+    const int rc = m4g_writer_create_v2(v2.level, device, &w_);
+    if (rc != M4G_OK)
+      throw std::runtime_error(std::string("m4g_writer_create_v2: ") + m4g_strerror(rc) + " (" + m4g_last_error() + ")");
+  }
   ~GPUWriter() { m4g_writer_destroy(w_); }
   GPUWriter(const GPUWriter &) = delete;
   GPUWriter &operator=(const GPUWriter &) = delete;

@@ -286,6 +286,18 @@ func newWriter(dst io.Writer, q M4, format, blockSize int, mtime uint32) *Writer
 // BlockSize: blockSize} (brotli_test.go:626-649).
 func NewBrotliWriter(dst io.Writer, q M4, blockSize int) *Writer { return newWriter(dst, q, FormatBrotli, blockSize, 0) }
 
+// NewWriterV2 is brotli.NewWriterV2(dst, level) for levels 5-9 (writer.go:126-161): Bargain1 / Bargain2 / Bargain3 and
+// brotli.Encoder on the GPU behind matchfinder.Writer's Write / Close / Reset (m4g_writer_create_v2).
+func NewWriterV2(dst io.Writer, level int) *Writer {
+	var h *C.m4g_writer
+	if rc := C.m4g_writer_create_v2(C.int(level), 0, &h); rc != 0 {
+		fail("m4g_writer_create_v2", rc)
+	}
+	w := &Writer{Dest: dst, w: h, buf: make([]byte, 1<<20)}
+	runtime.SetFinalizer(w, func(w *Writer) { C.m4g_writer_destroy(w.w) })
+	return w
+}
+
 func flateM4(level int) M4 {
 	chain, ok := map[int]int{5: 8, 6: 16, 7: 32}[level] // flate/writer.go:33-46
 	if !ok {

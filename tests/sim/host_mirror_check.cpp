@@ -105,6 +105,21 @@ int main() {
       }
     }
   }
+  // NewWriterV2(dst, 5) as a handle: ragged Writes and one Write give the same stream
+  {
+    Sink v1, v2;
+    matchfinder::GPUWriter<Sink> wa(&v1, matchfinder::GPUWriter<Sink>::V2{5});
+    wa.Write(data.data(), 70001);
+    wa.Write(data.data() + 70001, data.size() - 70001);
+    wa.Close();
+    wa.Reset(&v2);
+    wa.Write(data.data(), data.size());
+    wa.Close();
+    if (v1.v.size() < 8 || v1.v != v2.v || v1.v.size() > data.size() / 4) {
+      std::puts("FAIL writer v2");
+      return 1;
+    }
+  }
   std::puts("ok");
   return 0;
 }
