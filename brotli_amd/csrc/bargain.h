@@ -219,7 +219,7 @@ __device__ unsigned long long kb_stats[8]; // rep evals, add_match calls, far ca
 #endif
 
 template <int NT>
-__global__ __launch_bounds__(64) void kb_parse(
+__global__ __launch_bounds__(64, 8) void kb_parse(
     const uint8_t *__restrict__ src_base, uint64_t src_total, const uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, const BBlock *__restrict__ blocks, uint32_t nblocks,
     const float *__restrict__ byte_cost, uint2 *__restrict__ ws_ld, float *__restrict__ ws_cost, uint32_t ws_stride,
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(64) void kb_parse(
   uint2 *gLD = ws_ld + (size_t)blockIdx.x * ws_stride;
   float *gC = ws_cost + (size_t)blockIdx.x * ws_stride;
 
+  // (the grid is what the GPU holds at once, bargain_host.h; blocks are equally long but for the last of a stream)
 #pragma unroll 1
   for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
     const BBlock B = blocks[b];

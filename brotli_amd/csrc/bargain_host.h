@@ -4,7 +4,7 @@
 
 namespace {
 
-constexpr int kKbWavesPerCu = 32; // 4 KiB of LDS and <= 64 VGPRs per wave
+constexpr int kKbWavesPerCu = 32; // 4 KiB of LDS and <= 64 VGPRs per wave (__launch_bounds__(64, 8))
 
 struct BargainDesc {
   int nt = 0;
@@ -125,7 +125,15 @@ extern "C" int m4g_bargain_create(const m4g_bargain_params *params, int device, 
     m4g_bargain_destroy(g);
     return fail(M4G_ERR_HIP, "hipGetDeviceProperties failed");
   }
-  g->nwaves = (uint32_t)std::min<size_t>(g->max_blocks, (size_t)prop.multiProcessorCount * kKbWavesPerCu);
+  // the grid is what the GPU holds at once: a workgroup that had to wait for a slot would run its blocks alone at the end
+  int per_cu = 0;
+  const void *fn = d.nt == 1 ? reinterpret_cast<const void *>(kb_parse<1>)
+                             : d.nt == 2 ? reinterpret_cast<const void *>(kb_parse<2>) : reinterpret_cast<const void *>(kb_parse<3>);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    per_cu = kKbWavesPerCu;
+  }
+  g->nwaves = (uint32_t)std::min<size_t>(g->max_blocks, (size_t)prop.multiProcessorCount * std::min(per_cu, kKbWavesPerCu));
   g->ws_stride = (uint32_t)((std::min<size_t>(d.P.block_size, max_chunk_bytes) + 1 + 127) & ~(size_t)63);
   g->stage_cap = d.P.block_size / 3 + 2;
   bool ok = true;
