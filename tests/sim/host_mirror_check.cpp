@@ -109,8 +109,8 @@ int main() {
   {
     Sink v1, v2;
     matchfinder::GPUWriter<Sink> wa(&v1, matchfinder::GPUWriter<Sink>::V2{5});
-    wa.Write(data.data(), 70001);
-    wa.Write(data.data() + 70001, data.size() - 70001);
+    wa.Write(data.data(), 20005);
+    wa.Write(data.data() + 20005, data.size() - 20005);
     wa.Close();
     wa.Reset(&v2);
     wa.Write(data.data(), data.size());
