@@ -104,9 +104,10 @@ extern "C" int m4g_bargain_create(const m4g_bargain_params *params, int device, 
   if (int rc = bargain_desc(params, &d)) return rc;
   if (!max_chunks || !max_total_bytes || !max_chunk_bytes) return fail(M4G_ERR_BAD_PARAM, "zero capacity");
   if (max_chunk_bytes >= (1ull << 31)) return fail(M4G_ERR_TOO_LARGE, "chunks of 2 GiB or more");
-  if (d.P.skip && (d.P.block_size & 1) && max_chunk_bytes > 2ull * d.P.max_distance)
-    // bargain1.go:159 tests the parity of the HISTORY position, which a slide of odd length flips
-    return fail(M4G_ERR_BAD_PARAM, "Skip with an odd block_size needs chunks of at most 2 * max_distance bytes");
+  if (d.P.skip && ((d.P.block_size | d.P.max_distance) & 1) && max_chunk_bytes > 2ull * d.P.max_distance)
+    // bargain1.go:159 tests the parity of the HISTORY position, which a slide of odd length flips: the first slide
+    // drops k * block_size - MaxDistance bytes, every later one a multiple of block_size (bargain1.go:66-70)
+    return fail(M4G_ERR_BAD_PARAM, "Skip with an odd block_size or MaxDistance needs chunks of at most 2 * max_distance bytes");
   if (int rc = check_device(device)) return rc;
   HIP_TRY(hipSetDevice(device));
   if (int rc = k1_prepare()) return rc;

@@ -451,7 +451,9 @@ int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uin
 typedef struct m4g_bargain_params {
   int32_t variant;      /* 1 = Bargain1, 2 = Bargain2, 3 = Bargain3 */
   int32_t max_distance; /* MaxDistance; 0 = 1 << 16 (bargain1.go:39-41); NewWriterV2 uses 1 << 20 */
-  int32_t skip;         /* Skip (bargain1.go:20-22, 159) */
+  int32_t skip;         /* Skip (bargain1.go:20-22, 159); with an odd block_size or max_distance only for
+                         * chunks of at most 2 x max_distance bytes (a slide of odd length would flip the
+                         * parity the reference tests): M4G_ERR_BAD_PARAM otherwise */
   int32_t block_size;   /* Writer.BlockSize; 0 = 1 << 16 (writer.go:156); 3851 .. 1 << 24 */
 } m4g_bargain_params;
 typedef struct m4g_bargain m4g_bargain;
