@@ -685,11 +685,20 @@ def main():
         pin_in.close()
         pin_out.close()
     if rank == 0 and world == 1 and args.flate_chunks > 0 and args.kind == "text" and not args.no_gpu_encode:
-        out["gpu_flate"] = flate_leg(host, n, min(C, args.flate_chunks), dev, local_rank, args.no_cpu_baseline)
+        try:
+            out["gpu_flate"] = flate_leg(host, n, min(C, args.flate_chunks), dev, local_rank, args.no_cpu_baseline)
+        except Exception as e:  # a side leg must never cost the bench line
+            out["gpu_flate"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and args.writer_mib > 0 and args.kind == "text" and not args.no_gpu_encode:
-        out["gpu_writer"] = writer_leg(host, min(n * C, args.writer_mib << 20), local_rank)
+        try:
+            out["gpu_writer"] = writer_leg(host, min(n * C, args.writer_mib << 20), local_rank)
+        except Exception as e:
+            out["gpu_writer"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and args.bargain_chunks > 0 and args.kind == "text" and not args.no_gpu_encode:
-        out["gpu_bargain"] = bargain_leg(host, n, min(C, args.bargain_chunks), dev, local_rank, args.no_cpu_baseline)
+        try:
+            out["gpu_bargain"] = bargain_leg(host, n, min(C, args.bargain_chunks), dev, local_rank, args.no_cpu_baseline)
+        except Exception as e:  # a side leg must never cost the bench line
+            out["gpu_bargain"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
