@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
     // as cheap: per 64 arrivals, one compare and one ballot find it.
     // start_cost = the cost of arrival ks at the time of the call (0 for ks = 0); top_first: look at arrival
     // k_top alone before the rest (the loop stops there when a match found at the previous position already
-    // covers this one, which is the rule for the backward-extended form).
+    // covers this one at a lower cost, which is the rule for the backward-extended form and common for the plain one).
     auto add_match = [&](uint32_t ks, float start_cost, int32_t k_top, uint32_t dist, uint32_t unmatched, float dcost,
                          bool top_first) {
       KB_COUNT(add);
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
             KB_COUNT(repm);
             uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)rep_f, (int)t);
             if (rep_long >> t & 1) end = wave_extend((uint64_t)(i - pd) + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
-            add_match(r, a_cost, (int32_t)(end - hs), pd, unmatched, 0.f, false);
+            add_match(r, a_cost, (int32_t)(end - hs), pd, unmatched, 0.f, true);
           }
         }
 
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
                         dcost, true);
             // (the extended form may have rewritten arrival r when delta >= 3: read its cost again)
             add_match(r, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(C0), (int)t)), k_top, dist,
-                      unmatched, dcost, false);
+                      unmatched, dcost, true);
             const uint32_t end = hs + (uint32_t)k_top;
             nos = max(nos, max((int32_t)i + 1, (int32_t)end - (int32_t)P.overlap));
           }
