@@ -203,6 +203,16 @@ def test_hand_cases():
     # offset 0 < i, val 0 == the four zero bytes): distance 1 from the first searched position on
     m = OracleBargain(1, 1 << 20).FindMatches(bytes(64)).tolist()
     assert m == [[1, 63, 1]]
+    # the repeat-distance probe (bargain1.go:148-157), traced by hand: P, 8 other bytes, P[:10], '#', P[11:], 8 other
+    # bytes.  Position 28 finds P through its hash: match of 10 at distance 28 (cost 4 + Len(28) + Len(28) = 14 bits
+    # against ~48 for the literals).  '#' is a literal; at position 39 the arrival is that literal (unmatched 1), the
+    # previous distance is 28 and src[11:15] == src[39:43]: a repeat match of 9 at cost 4 + Len(1) + 0, which the hash
+    # candidate of the same position (the same match at 5 bits more) cannot replace (:99-100).  No room to hash in the
+    # last 7 positions: the tail is one literal run, attached to an empty Match (:195-200).
+    P = b"0123456789abcdefghij"
+    for variant in (1, 2, 3):
+        m = OracleBargain(variant, 1 << 20).FindMatches(P + b"ABCDEFGH" + P[:10] + b"#" + P[11:] + b"KLMNOPQR").tolist()
+        assert m == [[28, 10, 28], [1, 9, 28], [8, 0, 0]]
     # a second block continues with the first block's table and history
     z = OracleBargain(1, 1 << 20)
     z.FindMatches(b"0123456789abcdef" * 2)
