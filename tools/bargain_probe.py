@@ -19,7 +19,14 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 kind = sys.argv[4] if len(sys.argv) > 4 else "text"
 n, bs = 1 << 20, 1 << 16
 host = np.empty(n * chunks, dtype=np.uint8)
-synth.fill(host, n, 0, kind, 16)
+if kind in ("text", "log"):
+    synth.fill(host, n, 0, kind, 16)
+elif kind == "random":
+    host[:] = np.random.default_rng(1).integers(0, 256, size=host.size, dtype=np.uint8)
+elif kind == "zeros":
+    host[:] = 0
+else:
+    raise SystemExit("kind: text | log | random | zeros")
 d_src = torch.empty(n * chunks + 64, dtype=torch.uint8, device="cuda")
 d_src[:n * chunks].copy_(torch.from_numpy(host))
 off = np.arange(chunks + 1, dtype=np.uint64) * n
