@@ -218,6 +218,9 @@ __device__ unsigned long long kb_stats[8]; // rep evals, add_match calls, far ca
 #define KB_COUNT(k) ((void)0)
 #endif
 
+#define KB_LIKELY(x) __builtin_expect(!!(x), 1)
+#define KB_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 template <int NT>
 __global__ __launch_bounds__(64, 8) void kb_parse(
     const uint8_t *__restrict__ src_base, uint64_t src_total, const uint32_t *__restrict__ chain_base,
@@ -307,12 +310,12 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
       return idx < 64 ? x0 : x1;
     };
     auto uread_d = [&](uint32_t k) -> uint32_t { // k wave-uniform
-      if (k - b0 < 128u) return rget(D0, D1, k - b0);
+      if (KB_LIKELY(k - b0 < 128u)) return rget(D0, D1, k - b0);
       KB_COUNT(pdfar);
       return (uint32_t)__builtin_amdgcn_readfirstlane((int)read_d(k));
     };
     auto uread_c = [&](uint32_t k) -> float {
-      if (k - b0 < 128u) return __uint_as_float(rget(__float_as_uint(C0), __float_as_uint(C1), k - b0));
+      if (KB_LIKELY(k - b0 < 128u)) return __uint_as_float(rget(__float_as_uint(C0), __float_as_uint(C1), k - b0));
       return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(read_c(k))));
     };
 
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
         const float ct = __uint_as_float(rget(__float_as_uint(C0), __float_as_uint(C1), (uint32_t)(k_top - r_lo)));
         if (ct > 0.f && ct <= cost) return;
       }
-      if (k_lo >= r_lo && k_top <= r_lo + 63) { // the whole range is in the first register row
+      if (KB_LIKELY(k_lo >= r_lo && k_top <= r_lo + 63)) { // the whole range is in the first register row
         const int32_t k0 = r_lo + (int32_t)lane;
         const bool in0 = k0 >= k_lo && k0 <= k_top;
         const unsigned long long sm0 = __builtin_amdgcn_ballot_w64(in0 && C0 > 0.f && C0 <= cost);
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
         L0 = w0 ? (uint32_t)k0 - ks : L0, D0 = w0 ? dist : D0, C0 = w0 ? cost : C0;
         return;
       }
-      if (k_lo >= r_lo && k_top <= r_hi) { // the whole range is in registers: no branch below
+      if (KB_LIKELY(k_lo >= r_lo && k_top <= r_hi)) { // the whole range is in registers: no branch below
         const int32_t k0 = r_lo + (int32_t)lane, k1 = k0 + 64;
         const bool in1 = k1 >= k_lo && k1 <= k_top, in0 = k0 >= k_lo && k0 <= k_top;
         const unsigned long long sm1 = __builtin_amdgcn_ballot_w64(in1 && C1 > 0.f && C1 <= cost);
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
         uint32_t pd = 0;
         if (unmatched != 0 && r > unmatched) { // arrival r - unmatched is below r: first register row, or older
           const uint32_t kb = r - unmatched;
-          pd = kb >= b0 ? (uint32_t)__builtin_amdgcn_readlane((int)D0, (int)(kb - b0)) : uread_d(kb);
+          pd = KB_LIKELY(kb >= b0) ? (uint32_t)__builtin_amdgcn_readlane((int)D0, (int)(kb - b0)) : uread_d(kb);
         }
 #if defined(KB_EXP) && KB_EXP >= 2
         pd = 0;
@@ -523,17 +526,17 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
           L1 = w1 ? unmatched + 1 : L1, D1 = w1 ? 0u : D1, C1 = w1 ? c1 : C1;
           nbu = relax || rget(D0, D1, t + 1) == 0;
         }
-        if (!(vmask >> t & 1)) continue;
+        if (KB_UNLIKELY(!(vmask >> t & 1))) continue;
 
         // repeat match (bargain1.go:148-157)
         if (pd != 0 && pd != rget(D0, D1, t + 4)) {
-          if (pd != rep_pd) { // the 4-byte probe at all 64 positions of the batch: one load
+          if (KB_UNLIKELY(pd != rep_pd)) { // the 4-byte probe at all 64 positions of the batch: one load
             KB_COUNT(rep);
             const bool eq = valid && i_l >= pd && kb_ld32(src + (i_l - pd)) == cv32;
             rep_mask = __builtin_amdgcn_ballot_w64(eq);
             rep_pd = pd;
             rep_long = 0;
-            if (rep_mask) { // (rare: 6 probes in 10000 hit) how far the matches run
+            if (KB_UNLIKELY(rep_mask != 0)) { // (rare: 6 probes in 10000 hit) how far the matches run
               bool lng = false;
               uint32_t f = 0;
               if (eq) {
@@ -544,10 +547,10 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
               rep_long = __builtin_amdgcn_ballot_w64(lng);
             }
           }
-          if (rep_mask >> t & 1) {
+          if (KB_UNLIKELY(rep_mask >> t & 1)) {
             KB_COUNT(repm);
             uint32_t end = i + 4 + (uint32_t)__builtin_amdgcn_readlane((int)rep_f, (int)t);
-            if (rep_long >> t & 1) end = wave_extend((uint64_t)(i - pd) + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
+            if (KB_UNLIKELY(rep_long >> t & 1)) end = wave_extend((uint64_t)(i - pd) + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP);
             add_match(r, a_cost, (int32_t)(end - hs), pd, unmatched, 0.f, true);
           }
         }
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
             int32_t k_top = __builtin_amdgcn_readlane((int)cktop[q], (int)t);
             uint32_t delta = (uint32_t)__builtin_amdgcn_readlane((int)cb[q], (int)t);
             const float dcost = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cdc[q]), (int)t));
-            if ((flm[q] | blm[q]) >> t & 1) { // extensions beyond what phase A compared
+            if (KB_UNLIKELY((flm[q] | blm[q]) >> t & 1)) { // extensions beyond what phase A compared
               const uint32_t c = i - dist;
               if (flm[q] >> t & 1)
                 k_top = (int32_t)(wave_extend((uint64_t)c + 4 + KB_FCAP, (uint64_t)i + 4 + KB_FCAP) - hs);
