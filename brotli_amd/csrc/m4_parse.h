@@ -26,6 +26,12 @@
 #define M4G_HD inline
 #endif
 
+// Counting hooks for tools/analysis/parse_stats.cpp (host analysis only): empty everywhere else.
+#ifndef M4G_STAT
+#define M4G_STAT(k) ((void)0)
+#define M4G_STATN(k, n) ((void)0)
+#endif
+
 namespace m4g {
 
 struct ParseParams {
@@ -105,7 +111,9 @@ M4G_HD int64_t score(const AbsMatch &m, int32_t cost) {
 // m4.go:293-324: first index >= j where src[i+k] != src[j+k], or len.
 template <class Mem>
 M4G_HD int32_t extend_fwd(const Mem &M, int32_t len, int32_t i, int32_t j) {
+  M4G_STAT(21);
   while (j + 8 < len) {
+    M4G_STAT(22);
     uint64_t a = M.ld64(i), b = M.ld64(j);
     if (a != b) return j + (int32_t)(__builtin_ctzll(a ^ b) >> 3);
     i += 8;
@@ -125,6 +133,7 @@ M4G_HD int32_t extend_bwd(const Mem &M, int32_t pos, int32_t cand, int32_t nb, i
   // 8 bytes per step while 8 more fit (maxb <= cand and maxb <= pos: the reads stay inside the buffer);
   // a match source is far memory, so every step is a round trip -- bytewise this loop was what made
   // long back-extensions (repeated paragraphs) crawl
+  M4G_STAT(23);
   while (nb + 8 <= maxb) {
     const uint64_t x = M.ld64(pos - nb - 8) ^ M.ld64(cand - nb - 8);
     if (x != 0) return nb + (int32_t)(__builtin_clzll(x) >> 3);
@@ -301,8 +310,10 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
   uint64_t pc_bytes = 0;
   int32_t pc_base = -0x40000000;
   while (i < stop) {
+    M4G_STAT(0);
     // A. m4.go:113-126
     if (S.m0.end != 0 && i >= S.m0.end) {
+      M4G_STAT(1);
       flush(S, P, sink);
       if (STOP_AT_FLUSH) {
         S.i = i;
@@ -310,6 +321,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       }
     }
     const bool was_empty = S.m0.end == 0;
+    if (was_empty) M4G_STAT(2); else M4G_STAT(26);
 
     // ---- what this iteration may need from far memory ----------------------
     const int32_t p = i + 1;
@@ -333,7 +345,10 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
 
     // B. m4.go:128-138 repeat match one byte after the current position
     if (probe_err) S.error |= kStateErrRange; // the Go code would panic on the slice bounds
+    if (probe_load) M4G_STAT(4);
+    if (cand_fast) M4G_STAT(27);
     if (do_probe) {
+      M4G_STAT(3);
       uint32_t cw;
       if (pc_off <= 4) {
         cw = (uint32_t)(pc_bytes >> (8 * pc_off));
@@ -346,8 +361,10 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       }
       AbsMatch m;
       if (cw == M.ld32(p) && match_at(M, len, p, c, S.next_emit + 1, m)) {
+        M4G_STAT(5);
         if (m.end >= len) S.error |= kStateTouchedEnd;
         if (m.end - m.start >= P.min_length) {
+          M4G_STAT(6);
           S.m0 = m;
           if (S.first_i < 0) S.first_i = i;
         }
@@ -356,11 +373,13 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
 
     // D. m4.go:149-151: a match set just now makes i an interior position
     if (was_empty && S.m0.end != 0 && i != S.m0.end + 2 - P.hash_len) {
+      M4G_STAT(7);
       i = next_pos(S, P, i);
       continue;
     }
     // m4.go:152-154
     if (!cand_ok) {
+      M4G_STAT(8);
       i = next_pos(S, P, i);
       continue;
     }
@@ -370,15 +389,18 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     int64_t cur_score = 0;
     AbsMatch m;
     if (ce & kChainMaybe) {
+      M4G_STAT(9);
       const bool hit = cand_fast ? match_regs(M, len, i, cand, S.next_emit, cf, cf2, cand_fast2, cb, m)
                                  : match_at(M, len, i, cand, S.next_emit, m);
       if (hit) {
+        M4G_STAT(10);
         if (!S.have_prev && m.start == S.next_emit) S.error |= kStateHitLo;
         if (m.end >= len) S.error |= kStateTouchedEnd;
       }
       if (hit && m.end - m.start > P.min_length) {
         int64_t sc = score(m, P.distance_bit_cost);
         if (sc > 0) {
+          M4G_STAT(11);
           cur = m;
           cur_score = sc;
         }
@@ -390,6 +412,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     for (int32_t j = 0; j < P.chain_length; j++) {
       uint32_t dd = next_entry & kChainDelta;
       if (dd == 0) break;
+      M4G_STAT(24);
       // Go: candidate -= int(delta) in 64-bit; dd > cand means candidate <= 0
       if (dd >= (uint32_t)cand) break;
       cand -= (int32_t)dd;
@@ -405,6 +428,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
         hop_hit = match_at(M, len, i, cand, S.next_emit, m);
       }
       if (hop_hit) {
+        M4G_STAT(25);
         if (!S.have_prev && m.start == S.next_emit) S.error |= kStateHitLo;
         if (m.end >= len) S.error |= kStateTouchedEnd;
         if (m.end - m.start > P.min_length) {
@@ -418,35 +442,44 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     }
     // m4.go:183-185
     if (cur.end - cur.start < P.min_length) {
+      M4G_STAT(12);
       i = next_pos(S, P, i);
       continue;
     }
 
     // F. m4.go:187-199
+    M4G_STAT(13);
     int64_t penalty = 0;
     if (S.m0.end != 0) {
       penalty = 275;
       if (cur.start <= S.m1.end) penalty = 0;
     }
     if (cur_score <= score(S.m0, P.distance_bit_cost) + penalty) {
+      M4G_STAT(14);
       i = next_pos(S, P, i);
       continue;
     }
 
     // m4.go:201-209
+    M4G_STAT(15);
     AbsMatch m2 = S.m1;
     S.m1 = S.m0;
     S.m0 = cur;
     if (S.first_i < 0) S.first_i = i;
     if (m2.end != 0) {
       // G. m4.go:211-259
+      M4G_STAT(16);
       if (S.m0.start < m2.end) {
+        M4G_STAT(17);
         S.m1 = m2;
       } else if (S.m0.start < m2.end + P.min_length) {
+        M4G_STAT(18);
         emit(S, m2, sink);
         S.m1 = AbsMatch{0, 0, 0};
       } else {
+        M4G_STAT(19);
         if (m2.end > S.m1.start) {
+          M4G_STAT(20);
           m2.end = S.m1.start;
           int32_t mlen = m2.end - m2.start;
           if (P.chain_length > 0 && mlen >= P.min_length) {
