@@ -15,6 +15,7 @@
 
 #include "m4_parse.h"
 #include "m4_spec.h"
+#include "m4_fast.h"
 
 namespace m4g {
 
@@ -599,6 +600,12 @@ struct StagedMem {
     if (o < (uint32_t)K3_W) return lch[o];
     return chain[p];
   }
+  // light filter of parse_range: p in [w0, w0 + K3_W), resp. p + 4 <= w0 + K3_W + K3_FWD
+  __device__ __forceinline__ uint32_t near_chain(int32_t p) const { return lch[p - w0]; }
+  __device__ __forceinline__ uint32_t near32(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + K3_BACK), w = o >> 2;
+    return __builtin_amdgcn_alignbyte(lsrc[w + 1], lsrc[w], o & 3);
+  }
 };
 
 // Forward extension of a speculative lane.  Same result as the generic one,
@@ -740,7 +747,11 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (row_on) {
       M.w0 = w0;
+#ifdef M4G_K3_NOLIGHT
       parse_range<false>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
+#else
+      parse_range<false, true>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
+#endif
       aborted = len_eff < len && (S.error & kStateTouchedEnd);
     }
   }
@@ -761,6 +772,303 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   if (sink.n > L.slot) atomicOr(errors, 2u);
   // a range error of a speculative parse may come from its guessed state: only
   // block 0, whose parse is the true one, reports here; k3b / k3c report theirs
+  if (k == 0 && !aborted && (S.error & kStateErrRange)) atomicOr(errors, 1u);
+}
+
+// ---------------------------------------------------------------------------
+// K3a for ChainLength == 0: the same speculative parse, one lane per sub-block, but the wave
+// advances by EVENTS (m4_fast.h) and every lane has its own window.
+//
+// k3a_spec above runs parse_range in lockstep epochs of 16 positions: each wave-iteration executes
+// the union of the loop's paths (~475 instructions) and waits for far memory, ~700 times per
+// sub-block, although a lane has something to do at only ~200 of its 1024 positions
+// (tools/analysis/parse_stats.cpp), and a lane that jumps over a match idles until the epoch ends.
+// Here one ROUND of the wave is:
+//   1. fast_light   every running lane skips to its next event (straight-line code, LDS only);
+//   2. fast_issue   flushes, and names the far bytes the event needs; lanes whose position has
+//                   left their window ask for a new one (16 positions, aligned);
+//   3. ONE batch of loads: probe / candidate bytes of the event lanes and the windows (up to
+//                   KF_MAX_ROWS rows, copied cooperatively in 16-byte pieces, the piece -> row
+//                   assignment through a list in LDS); one wait;
+//   4. fast_complete  candidate evaluation and the queue logic on registers;
+//   5. lanes whose iteration needs the generic code (a probe that hits, a long match, three pending
+//      matches: ~6 per KiB) PARK; when KF_RARE_BATCH of them wait, or nobody else can run, the wave
+//      runs parse_range for exactly that one iteration of each.
+// A lane takes ~2 rounds per match (flush + probe bytes, candidate), the wave ~1/3 of the rounds it
+// took iterations, and a round issues fewer instructions than an iteration did.
+// ---------------------------------------------------------------------------
+constexpr int KF_BACK = 16, KF_FWD = 16;
+constexpr int KF_SRC_BYTES = KF_BACK + KF_W + KF_FWD; // 48
+constexpr int KF_SRC_PIECES = KF_SRC_BYTES / 16;      // 3
+constexpr int KF_CH_PIECES = KF_W / 4;                // 4
+constexpr int KF_PIECES = KF_SRC_PIECES + KF_CH_PIECES;
+constexpr int KF_SRC_DW = KF_SRC_BYTES / 4 + 1;       // 13: odd row strides keep the banks apart
+constexpr int KF_CH_DW = KF_W + 1;                    // 17
+#ifndef M4G_KF_ITERS
+#define M4G_KF_ITERS 3
+#endif
+constexpr int KF_ITERS = M4G_KF_ITERS;                // 16-byte pieces per lane and round
+constexpr int KF_MAX_ROWS = KF_ITERS * 64 / KF_PIECES; // windows filled per round
+#ifndef M4G_KF_MINWAVES
+#define M4G_KF_MINWAVES 4
+#endif
+#ifndef M4G_KF_RARE_BATCH
+#define M4G_KF_RARE_BATCH 8
+#endif
+constexpr int KF_RARE_BATCH = M4G_KF_RARE_BATCH;
+static_assert(KF_SRC_DW % 2 == 1 && KF_CH_DW % 2 == 1, "odd row strides");
+
+struct FastMem {
+  const uint8_t *src;
+  const uint32_t *chain;
+  const uint32_t *lsrc; // LDS row of this lane: bytes [w0 - KF_BACK, w0 + KF_W + KF_FWD)
+  const uint32_t *lch;  // LDS row of this lane: chain[w0 .. w0 + KF_W)
+  int32_t w0;
+  uint32_t hm;          // bit k: fast_heavy(chain[w0 + k])
+  int32_t give_up_at;
+  // --- the window, no range checks (m4_fast.h) ---
+  __device__ __forceinline__ uint32_t near_chain(int32_t p) const { return lch[p - w0]; }
+  __device__ __forceinline__ uint32_t heavy_mask(int32_t p) const { return hm >> (p - w0); }
+  __device__ __forceinline__ uint32_t near32(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + KF_BACK), w = o >> 2;
+    return __builtin_amdgcn_alignbyte(lsrc[w + 1], lsrc[w], o & 3);
+  }
+  __device__ __forceinline__ uint64_t near64(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + KF_BACK), w = o >> 2, sh = o & 3;
+    const uint32_t d0 = lsrc[w], d1 = lsrc[w + 1], d2 = lsrc[w + 2];
+    return ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sh);
+  }
+  // --- the generic accessor (parse_range for the parked iterations) ---
+  __device__ __forceinline__ uint8_t ld8(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + KF_BACK);
+    if (o < (uint32_t)KF_SRC_BYTES) return (uint8_t)(lsrc[o >> 2] >> (8 * (o & 3)));
+    return src[p];
+  }
+  __device__ __forceinline__ uint32_t ld32(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + KF_BACK);
+    if (o <= (uint32_t)(KF_SRC_BYTES - 4)) return near32(p);
+    return m4g::ld32(src + p);
+  }
+  __device__ __forceinline__ uint64_t ld64(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0 + KF_BACK);
+    if (o <= (uint32_t)(KF_SRC_BYTES - 8)) return near64(p);
+    return m4g::ld64(src + p);
+  }
+  __device__ __forceinline__ uint64_t far64(int32_t p) const { return m4g::ld64(src + p); }
+  __device__ __forceinline__ uint32_t chain_at(int32_t p) const {
+    const uint32_t o = (uint32_t)(p - w0);
+    if (o < (uint32_t)KF_W) return lch[o];
+    return chain[p];
+  }
+};
+
+// (the give-up shortcut of the StagedMem overload above)
+__device__ __forceinline__ int32_t extend_fwd(const FastMem &M, int32_t len, int32_t i, int32_t j) {
+  int32_t run = 0;
+  while (j + 8 < len) {
+    const uint64_t a = M.ld64(i), b = M.ld64(j);
+    if (a != b) return j + (int32_t)(__builtin_ctzll(a ^ b) >> 3);
+    i += 8;
+    j += 8;
+    run += 8;
+    if (run == 256 && M.give_up_at > 0 && j + 16 < M.give_up_at) {
+      const int32_t d = M.give_up_at - 8 - j;
+      if (M.far64(i + d) == M.far64(j + d)) return M.give_up_at;
+    }
+  }
+  while (j < len && M.ld8(i) == M.ld8(j)) {
+    i++;
+    j++;
+  }
+  return j;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 16 bytes of a window row; pieces that reach past either end of the whole source buffer (the
+// first window of the first job, the last of the last) take the byte-wise path.
+__device__ __forceinline__ uint4 kf_load_src_piece(const uint8_t *src_base, int64_t g, int64_t total) {
+  if (__builtin_expect(g >= 0 && g + 16 <= total, 1)) {
+    uint4 v;
+    __builtin_memcpy(&v, src_base + g, 16);
+    return v;
+  }
+  return load_group(src_base, g, total);
+}
+
+// Requires L.kmax % 64 == 0 (the host rounds it): a wave's 64 sub-blocks belong to ONE job, so the
+// job's fields and everything derived from them are wave-uniform (scalar registers).
+__global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
+    const uint8_t *__restrict__ src_base, uint64_t src_total,
+    const uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, Rec *__restrict__ rs,
+    ParseState *__restrict__ E, BlockDesc *__restrict__ desc, uint32_t *__restrict__ errors,
+    int njobs, SpecLayout L, ParseParams P) {
+  __shared__ uint32_t lds_src[K3_THREADS * KF_SRC_DW];
+  __shared__ uint32_t lds_ch[K3_THREADS * KF_CH_DW];
+  __shared__ uint32_t lds_hm[K3_THREADS];
+  __shared__ uint2 lds_list[K3_THREADS]; // rows that get a window this round: {lane, first position}
+  const int lane = threadIdx.x;
+  const uint32_t wv = (uint32_t)k3_wave_of_block(blockIdx.x, gridDim.x, L.kmax);
+  const uint32_t wpj = L.kmax / K3_THREADS;
+  const uint32_t job = wv / wpj;
+  if (job >= (uint32_t)njobs) return; // (wave-uniform)
+  const uint32_t k = (wv - job * wpj) * K3_THREADS + lane;
+  const uint64_t t = (uint64_t)wv * K3_THREADS + lane;
+  const Job J = jobs[job];
+  const SpecGeom g = spec_geom(J.start, J.len, L.sub_block);
+  const bool active = k < (uint32_t)g.nblocks;
+  const int32_t bb = block_begin(g, active ? (int32_t)k : 0);
+  const int32_t be = block_end(g, active ? (int32_t)k : 0);
+  const int32_t len = (int32_t)J.len;
+  const int32_t len_eff = (int64_t)be + K3_EXT_LIMIT < (int64_t)len ? be + K3_EXT_LIMIT : len;
+  const uint8_t *jsrc = src_base + J.src_off;
+  const uint32_t *jchain = chain_base + J.chain_off;
+
+  RecSink sink{rs + t * L.slot, 0, L.slot};
+  ParseState S;
+  state_init(S, bb, (active && k == 0) ? J.seed_prev : 0u);
+  FastLane F;
+  fast_init(F);
+  FastMem M;
+  M.src = jsrc;
+  M.chain = jchain;
+  M.lsrc = lds_src + lane * KF_SRC_DW;
+  M.lch = lds_ch + lane * KF_CH_DW;
+  M.w0 = -0x40000000; // no window yet
+  M.hm = 0;
+  M.give_up_at = len_eff < len ? len_eff : 0;
+  bool done = !active, rare = false, aborted = false;
+  uint32_t round = 0;
+#ifdef M4G_KF_STATS
+  uint32_t n_rare = 0, n_fill = 0; // rounds that ran the parked batch / filled windows
+#endif
+
+  for (;;) {
+    // 1. to the next event
+    const bool run = !done && !rare;
+    int st = kFastDone;
+    if (run) {
+      st = fast_light(M, P, S, F, be, M.w0 + KF_W);
+      done = st == kFastDone;
+    }
+    const bool ev = run && st == kFastEvent;
+    bool needw = run && st == kFastWindow;
+    // 2. flush, and what the event needs
+    if (ev) {
+      const bool inw = (uint32_t)(S.i - M.w0) < (uint32_t)KF_W;
+      fast_issue(M, len_eff, P, S, F, sink, inw, M.w0);
+      needw = !inw;
+      rare = F.rare != 0;
+    }
+    if (__ballot(!done) == 0) break;
+
+    // 3. loads: windows (the rows take turns when more than KF_MAX_ROWS ask) ...
+    const unsigned long long wmask = __ballot(needw);
+    uint4 rv[KF_ITERS];
+    int npieces = 0;
+    bool served = false;
+    const int32_t nw0 = S.i & ~(KF_W - 1);
+    if (wmask) {
+#ifdef M4G_KF_STATS
+      n_fill++;
+#endif
+      const unsigned rot = (round * KF_MAX_ROWS) & 63u;
+      const unsigned long long wrot = (wmask >> rot) | (rot ? wmask << (64 - rot) : 0ull);
+      const unsigned rl = ((unsigned)lane - rot) & 63u; // this lane's place in the rotated order
+      const int rank = __builtin_popcountll(wrot & ((1ull << rl) - 1ull));
+      npieces = min(__builtin_popcountll(wmask), KF_MAX_ROWS) * KF_PIECES;
+      served = needw && rank < KF_MAX_ROWS;
+      if (served) {
+        lds_list[rank] = make_uint2((uint32_t)lane, (uint32_t)nw0);
+        lds_hm[lane] = 0;
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int it = 0; it < KF_ITERS; it++) {
+        rv[it] = make_uint4(0, 0, 0, 0);
+        if (it * 64 < npieces) { // (wave-uniform)
+          const int p = it * 64 + lane;
+          if (p < npieces) {
+            const int r = p / KF_PIECES, part = p - r * KF_PIECES;
+            const int32_t rw0 = (int32_t)lds_list[r].y;
+            if (part < KF_SRC_PIECES)
+              rv[it] = kf_load_src_piece(src_base, (int64_t)J.src_off + rw0 - KF_BACK + part * 16, (int64_t)src_total);
+            else
+              __builtin_memcpy(&rv[it], jchain + rw0 + (part - KF_SRC_PIECES) * 4, 16);
+          }
+        }
+      }
+    }
+    // ... and the events' far bytes
+    const bool lp = ev && F.ld_probe >= 0, lc = ev && F.ld_cand >= 0;
+    const uint64_t pl = M.far64(lp ? F.ld_probe : 0);
+    const uint64_t cb = M.far64(lc ? F.ld_cand - 8 : 0);
+    const uint64_t cf = M.far64(lc ? F.ld_cand : 0);
+    const uint64_t cf2 = M.far64(lc ? F.ld_cand + 8 : 0);
+
+    if (wmask) {
+#pragma unroll
+      for (int it = 0; it < KF_ITERS; it++) {
+        const int p = it * 64 + lane;
+        if (p < npieces) {
+          const int r = p / KF_PIECES, part = p - r * KF_PIECES;
+          const int row = (int)lds_list[r].x;
+          const bool is_ch = part >= KF_SRC_PIECES;
+          uint32_t *d = is_ch ? lds_ch + row * KF_CH_DW + (part - KF_SRC_PIECES) * 4 : lds_src + row * KF_SRC_DW + part * 4;
+          d[0] = rv[it].x, d[1] = rv[it].y, d[2] = rv[it].z, d[3] = rv[it].w;
+          const uint32_t bits = (uint32_t)fast_heavy(rv[it].x, P) | (uint32_t)fast_heavy(rv[it].y, P) << 1 |
+                                (uint32_t)fast_heavy(rv[it].z, P) << 2 | (uint32_t)fast_heavy(rv[it].w, P) << 3;
+          if (is_ch && bits) atomicOr(&lds_hm[row], bits << (4 * (part - KF_SRC_PIECES)));
+        }
+      }
+      wave_lds_sync();
+      if (served) {
+        M.w0 = nw0;
+        M.hm = lds_hm[lane];
+      }
+    }
+    // 4. the rest of the event's iteration
+    if (ev && !rare) {
+      fast_complete(M, len_eff, P, S, F, (uint32_t)(S.i - M.w0) < (uint32_t)KF_W, pl, cb, cf, cf2);
+      rare = F.rare != 0;
+      if (len_eff < len && (S.error & kStateTouchedEnd)) aborted = done = true, rare = false;
+    }
+    // 5. parked iterations, a batch at a time
+    const unsigned long long rmask = __ballot(rare);
+    if (__builtin_expect(rmask && (__builtin_popcountll(rmask) >= KF_RARE_BATCH || __ballot(!done && !rare) == 0), 0)) {
+#ifdef M4G_KF_STATS
+      n_rare++;
+#endif
+      if (rare) {
+        parse_range<false, false, false, false>(M, len_eff, P, S, S.i + 1, sink);
+        rare = false;
+        if (len_eff < len && (S.error & kStateTouchedEnd)) aborted = done = true;
+      }
+    }
+    round++;
+  }
+#ifdef M4G_KF_STATS
+  if (lane == 0) atomicAdd(errors + 13, round), atomicAdd(errors + 14, n_rare), atomicAdd(errors + 15, n_fill);
+#endif
+  if (!active) return;
+  if (aborted) {
+    S.error |= kStateAborted;
+    sink.n = 0;
+  } else if (k == (uint32_t)g.nblocks - 1) {
+    parse_finish(len, P, S, sink);
+  }
+  E[t] = S;
+  BlockDesc d;
+  d.n_spec = sink.n;
+  d.n_stitch = 0;
+  d.keep_from = 0;
+  d.out_off = 0;
+  desc[t] = d;
+  if (sink.n > L.slot) atomicOr(errors, 2u);
   if (k == 0 && !aborted && (S.error & kStateErrRange)) atomicOr(errors, 1u);
 }
 

@@ -98,6 +98,9 @@ struct GlobalMem {
   // read of a match source: far from the positions being walked
   M4G_HD uint64_t far64(int32_t p) const { return m4g::ld64(src + p); }
   M4G_HD uint32_t chain_at(int32_t p) const { return chain[p]; }
+  // reads the light filter of parse_range makes: positions the caller guarantees to be "near"
+  M4G_HD uint32_t near_chain(int32_t p) const { return chain[p]; }
+  M4G_HD uint32_t near32(int32_t p) const { return m4g::ld32(src + p); }
 };
 
 M4G_HD int32_t bitlen32(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
@@ -301,7 +304,22 @@ M4G_HD int32_t next_pos(const ParseState &S, const ParseParams &P, int32_t i) {
 // unconditionally (lanes that do not need them read position 0), before any
 // branch; the branches then work on registers.  Only rare continuations
 // (matches longer than 16 bytes, chain hops) read memory inside a branch.
-template <bool STOP_AT_FLUSH = false, class Mem, class Sink>
+//
+// LIGHT: most iterations do nothing but advance i -- a literal position whose table entry
+// cannot match (no entry, too far, check bits differ: m4.go:152-163 fall through to :183) and
+// whose repeat probe fails on bytes the lane already holds, or the one searched position inside
+// a pending match with such an entry.  With LIGHT every lane first runs through those in a loop
+// of a few instructions and only enters the full iteration below at a position where something
+// can happen (a flush is due, the entry may match, the probe needs bytes or hits).  The lanes of
+// a wave then execute the long body once per EVENT instead of once per position.  The skipped
+// iterations change no state but i, so the result is the same by construction.  Mem must serve
+// near_chain(i) and near32(i + 1) for i < stop without a range check.
+//
+// CHAIN = false compiles the chain walk (m4.go:166-181) and the re-search of a trimmed match
+// (m4.go:235-253) out -- for callers that know ChainLength == 0; FUSED = false reads a candidate's
+// bytes where they are used (match_at) instead of all together at the top of the iteration: less
+// code and fewer registers for callers that run a single, rare iteration (k3a_fast's parked lanes).
+template <bool STOP_AT_FLUSH = false, bool LIGHT = false, bool CHAIN = true, bool FUSED = true, class Mem, class Sink>
 M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseState &S,
                         int32_t stop, Sink &sink) {
   int32_t i = S.i;
@@ -310,6 +328,31 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
   uint64_t pc_bytes = 0;
   int32_t pc_base = -0x40000000;
   while (i < stop) {
+    if (LIGHT) {
+      bool event = false;
+      do {
+        if (S.m0.end != 0 && i >= S.m0.end) { // a flush is due
+          event = true;
+          break;
+        }
+        const uint32_t le = M.near_chain(i);
+        if ((le & kChainDelta) - 1u < (uint32_t)P.max_distance && ((le & kChainMaybe) || P.chain_length > 0)) {
+          event = true; // a candidate to look at
+          break;
+        }
+        if (S.m0.end == 0 && S.have_prev) {
+          const int32_t lc = i + 1 - (int32_t)S.prev_dist;
+          const uint32_t lo = (uint32_t)(lc - pc_base);
+          if (lc < 0 || lo > 4 || (uint32_t)(pc_bytes >> (8 * lo)) == M.near32(i + 1)) {
+            event = true; // the probe needs bytes, hits, or is out of range
+            break;
+          }
+        }
+        M4G_STAT(29);
+        i = next_pos(S, P, i);
+      } while (i < stop);
+      if (!event) break;
+    }
     M4G_STAT(0);
     // A. m4.go:113-126
     if (S.m0.end != 0 && i >= S.m0.end) {
@@ -329,19 +372,22 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     const bool do_probe = was_empty && S.have_prev && c >= 0;
     const bool probe_err = was_empty && S.have_prev && c < 0;
     const uint32_t pc_off = (uint32_t)(c - pc_base);
-    const bool probe_load = do_probe && pc_off > 4 && c + 8 <= len;
+    const bool probe_load = FUSED && do_probe && pc_off > 4 && c + 8 <= len;
 
     const uint32_t ce = M.chain_at(i);
     const uint32_t d = ce & kChainDelta;
     const bool cand_ok = d != 0 && d <= (uint32_t)P.max_distance;
     int32_t cand = i - (int32_t)d;
-    const bool cand_fast = cand_ok && (ce & kChainMaybe) && cand >= 8; // i+8 <= len always
+    const bool cand_fast = FUSED && cand_ok && (ce & kChainMaybe) && cand >= 8; // i+8 <= len always
     const bool cand_fast2 = cand_fast && i + 16 <= len;
 
-    const uint64_t pl = M.far64(probe_load ? c : 0);
-    const uint64_t cf = M.far64(cand_fast ? cand : 0);
-    const uint64_t cb = M.far64(cand_fast ? cand - 8 : 0);
-    const uint64_t cf2 = M.far64(cand_fast2 ? cand + 8 : 0);
+    uint64_t pl = 0, cf = 0, cb = 0, cf2 = 0;
+    if (FUSED) {
+      pl = M.far64(probe_load ? c : 0);
+      cf = M.far64(cand_fast ? cand : 0);
+      cb = M.far64(cand_fast ? cand - 8 : 0);
+      cf2 = M.far64(cand_fast2 ? cand + 8 : 0);
+    }
 
     // B. m4.go:128-138 repeat match one byte after the current position
     if (probe_err) S.error |= kStateErrRange; // the Go code would panic on the slice bounds
@@ -408,8 +454,8 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     }
     // m4.go:166-181.  The chain entry of a candidate and the bytes around it are
     // read together (one far round trip per hop instead of two dependent ones).
-    uint32_t next_entry = P.chain_length > 0 ? M.chain_at(cand) : 0u;
-    for (int32_t j = 0; j < P.chain_length; j++) {
+    uint32_t next_entry = CHAIN && P.chain_length > 0 ? M.chain_at(cand) : 0u;
+    for (int32_t j = 0; CHAIN && j < P.chain_length; j++) {
       uint32_t dd = next_entry & kChainDelta;
       if (dd == 0) break;
       M4G_STAT(24);
@@ -482,7 +528,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
           M4G_STAT(20);
           m2.end = S.m1.start;
           int32_t mlen = m2.end - m2.start;
-          if (P.chain_length > 0 && mlen >= P.min_length) {
+          if (CHAIN && P.chain_length > 0 && mlen >= P.min_length) {
             // m4.go:236-252: look for a closer source for the trimmed match
             int32_t pos = m2.start;
             for (;;) {

@@ -73,7 +73,7 @@ M4G_HD void spec_parse_block(const Mem &M, int32_t len, const ParseParams &P,
                              const SpecGeom &g, int32_t k, uint32_t seed_prev, ParseState &E,
                              Sink &sink) {
   state_init(E, block_begin(g, k), k == 0 ? seed_prev : 0u);
-  parse_range<false>(M, len, P, E, block_end(g, k), sink);
+  parse_range<false, true>(M, len, P, E, block_end(g, k), sink);
   if (k == g.nblocks - 1) parse_finish(len, P, E, sink);
 }
 

@@ -203,6 +203,8 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
     w.L.sub_block = sub;
   }
   w.L.kmax = (uint32_t)std::max<size_t>(1, (max_bytes + (size_t)w.L.sub_block - 1) / (size_t)w.L.sub_block);
+  // whole waves per job, so that the 64 sub-blocks of a wave belong to ONE job (k3a_fast needs it)
+  if (w.L.kmax > K3_THREADS) w.L.kmax = (w.L.kmax + K3_THREADS - 1) / K3_THREADS * K3_THREADS;
   // records a parse can emit while walking one sub-block: the matches are
   // disjoint and at least min_length long, plus the pending ones at entry and
   // the tail records of the last block.
@@ -303,8 +305,14 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
   const unsigned g3 = (unsigned)((lanes + K3_THREADS - 1) / K3_THREADS);
   // tuning aid: unused dynamic LDS per workgroup = fewer waves per CU = fewer chunks in flight per XCD
   static const unsigned k3a_pad = std::getenv("M4G_K3A_LDS_PAD") ? (unsigned)std::atoi(std::getenv("M4G_K3A_LDS_PAD")) : 0u;
-  hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
-                     w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
+  // ChainLength 0: the event-driven form of the same speculative parse (k3a_fast, m4_fast.h)
+  static const bool k3a_slow = std::getenv("M4G_K3A_EPOCHS") != nullptr;
+  if (P.chain_length == 0 && w.L.kmax % K3_THREADS == 0 && !k3a_slow)
+    hipLaunchKernelGGL(k3a_fast, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
+                       w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
+  else
+    hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
+                       w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
   HIP_TRY(hipGetLastError());
   if (w.L.kmax > 1) {
     hipLaunchKernelGGL(k3b_stitch, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
@@ -680,6 +688,8 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
     HIP_TRY(hipMemcpy(w, b->W.d_errors, sizeof(w), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "[m4g] k3c: %u scan steps, %u blocks accepted by the probe check, %u parsed serially, %u skipped (covered)\n",
                  w[4], w[5], w[6], w[7]);
+    if (w[13]) // builds with M4G_KF_STATS: k3a_fast's rounds, summed over its waves
+      std::fprintf(stderr, "[m4g] k3a_fast: %u wave-rounds, %u of them ran the parked batch, %u filled windows\n", w[13], w[14], w[15]);
     if (w[9] | w[10] | w[11] | w[12]) // builds with M4G_K3C_TIMING: wave time per path, summed over the chunks
       std::fprintf(stderr, "[m4g] k3c wave-ms: scan %.2f, covered skip %.2f, probe check %.2f, serial %.2f\n",
                    w[9] * 16 / 1e5, w[10] * 16 / 1e5, w[11] * 16 / 1e5, w[12] * 16 / 1e5);

@@ -17,6 +17,7 @@
 #include "../../brotli_amd/csrc/m4_spec.h"
 #define HAVE_SPEC 1
 #endif
+#include "../../brotli_amd/csrc/m4_fast.h"
 
 using namespace m4g;
 
@@ -25,6 +26,58 @@ struct VecSink {
   std::vector<Rec> v;
   void push(const Rec &r) { v.push_back(r); }
 };
+
+// Host stand-in for the device's FastMem (kernels.h): a window of KF_W positions, aligned like
+// the device's, over plain memory.  Reads beyond the buffer return zeros (the device window holds
+// whatever follows the chunk; m4_fast.h never lets those bytes decide anything).
+struct HostFastMem : GlobalMem {
+  int32_t n, w0;
+  const ParseParams *P;
+  uint32_t near_chain(int32_t p) const { return p >= 0 && p < n ? chain[p] : 0u; }
+  uint64_t near64(int32_t p) const {
+    uint64_t v = 0;
+    for (int k = 0; k < 8; k++)
+      if (p + k >= 0 && p + k < n) v |= (uint64_t)src[p + k] << (8 * k);
+    return v;
+  }
+  uint32_t near32(int32_t p) const { return (uint32_t)near64(p); }
+  uint32_t heavy_mask(int32_t p) const {
+    uint32_t m = 0;
+    for (int32_t q = p < 0 ? 0 : p; q < w0 + KF_W; q++)
+      if (q < n && fast_heavy(chain[q], *P)) m |= 1u << (q - p);
+    return m;
+  }
+};
+
+// k3a_fast (kernels.h) for one lane: the same cycle of fast_light / fast_issue / fast_complete,
+// the parked iteration run at once.  Returns false when the parse was given up (len_eff < n).
+template <class Sink>
+bool fast_lane_parse(const uint8_t *src, const uint32_t *chain, int32_t n, int32_t len_eff, const ParseParams &P,
+                     ParseState &S, int32_t be, Sink &sink) {
+  HostFastMem M;
+  M.src = src, M.chain = chain, M.n = n, M.P = &P;
+  M.w0 = -0x40000000;
+  GlobalMem G{src, chain};
+  FastLane F;
+  fast_init(F);
+  for (;;) {
+    const int st = fast_light(M, P, S, F, be, M.w0 + KF_W);
+    if (st == kFastDone) return true;
+    if (st == kFastWindow) {
+      M.w0 = S.i & ~(KF_W - 1);
+      continue;
+    }
+    const bool inw = (uint32_t)(S.i - M.w0) < (uint32_t)KF_W;
+    fast_issue(M, len_eff, P, S, F, sink, inw, S.i);
+    uint64_t pl = 0, cb = 0, cf = 0, cf2 = 0;
+    if (!F.rare && F.ld_probe >= 0) pl = ld64(src + F.ld_probe);
+    if (!F.rare && F.ld_cand >= 0) cb = ld64(src + F.ld_cand - 8), cf = ld64(src + F.ld_cand), cf2 = ld64(src + F.ld_cand + 8);
+    if (!inw) M.w0 = S.i & ~(KF_W - 1); // (the device may serve the window a round later: in_window = false then)
+    if (!F.rare) fast_complete(M, len_eff, P, S, F, inw, pl, cb, cf, cf2);
+    if (F.rare) parse_range<false, false>(G, len_eff, P, S, S.i + 1, sink);
+    if (len_eff < n && (S.error & kStateTouchedEnd)) return false;
+  }
+}
 
 void build_chain(const uint8_t *src, int32_t start, int32_t len, int hash_len, int table_bits,
                  std::vector<uint32_t> &table, uint32_t *chain) {
@@ -80,7 +133,13 @@ int64_t sim_find_matches_spec(const uint8_t *src, int32_t n, int max_distance, i
   std::vector<ParseState> E(K);
   for (int k = 0; k < K; k++) {
     VecSink sink;
-    spec_parse_block(M, n, P, g, k, seed_prev, E[k], sink);
+    if (P.chain_length == 0 && !std::getenv("SIM_NOFAST")) {
+      state_init(E[k], block_begin(g, k), k == 0 ? seed_prev : 0u);
+      fast_lane_parse(src, chain.data(), n, n, P, E[k], block_end(g, k), sink);
+      if (k == g.nblocks - 1) parse_finish(n, P, E[k], sink);
+    } else {
+      spec_parse_block(M, n, P, g, k, seed_prev, E[k], sink);
+    }
     RS[k] = std::move(sink.v);
   }
   std::vector<Rec> result = RS[0];
@@ -159,7 +218,10 @@ int64_t sim_find_matches_k3(const uint8_t *src, int32_t n, int max_distance, int
     RecSink sink{rs.data() + (size_t)k * slot, 0, slot};
     ParseState S;
     state_init(S, bb, k == 0 ? seed_prev : 0u);
-    parse_range<false>(M, len_eff, P, S, be, sink);
+    if (P.chain_length == 0 && !std::getenv("SIM_NOFAST"))
+      fast_lane_parse(src, chain.data(), n, len_eff, P, S, be, sink);
+    else
+      parse_range<false, true>(M, len_eff, P, S, be, sink);
     const bool aborted = len_eff < n && (S.error & kStateTouchedEnd);
     if (aborted) {
       S.error |= kStateAborted;

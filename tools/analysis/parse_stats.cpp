@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
   const char *names[] = {"iterations", "flush", "was_empty", "do_probe", "probe_load", "probe_4hit", "probe_accept",
     "exit_D_interior", "exit_no_cand", "maybe", "cand_hit", "cand_cur", "exit_short", "reach_F", "exit_F", "push",
     "resolve_G", "G_drop_mid", "G_emit_old", "G_default", "G_clip", "ext_fwd_calls", "ext_fwd_steps", "ext_bwd_calls",
-    "chain_hops", "hop_hit", "interior_iter", "far_reads", "maybe_nocandok"};
+    "chain_hops", "hop_hit", "interior_iter", "far_reads", "maybe_nocandok", "light_skips"};
   const double tot = (double)n * chunks;
   printf("bytes %.0f records %llu (%.1f B/rec)\n", tot, (unsigned long long)recs, tot / recs);
   for (unsigned k = 0; k < sizeof(names) / sizeof(*names); k++)
