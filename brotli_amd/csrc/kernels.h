@@ -787,6 +787,8 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
 //   1. fast_light   every running lane skips to its next event (straight-line code, LDS only);
 //   2. fast_issue   flushes, and names the far bytes the event needs; lanes whose position has
 //                   left their window ask for a new one (16 positions, aligned);
+//      a lane whose event needs nothing from far memory (a flush whose probe bytes were kept when
+//      the match was found) repeats 1 and 2 once in the same round;
 //   3. ONE batch of loads: probe / candidate bytes of the event lanes and the windows (up to
 //                   KF_MAX_ROWS rows, copied cooperatively in 16-byte pieces, the piece -> row
 //                   assignment through a list in LDS); one wait;
@@ -812,6 +814,10 @@ constexpr int KF_MAX_ROWS = KF_ITERS * 64 / KF_PIECES; // windows filled per rou
 #ifndef M4G_KF_MINWAVES
 #define M4G_KF_MINWAVES 4
 #endif
+#ifndef M4G_KF_PASSES
+#define M4G_KF_PASSES 2
+#endif
+constexpr int KF_PASSES = M4G_KF_PASSES; // events without far loads a lane may take per round (+1)
 #ifndef M4G_KF_RARE_BATCH
 #define M4G_KF_RARE_BATCH 8
 #endif
@@ -948,25 +954,33 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
 #endif
 
   for (;;) {
-    // 1. to the next event
-    const bool run = !done && !rare;
-    int st = kFastDone;
-    if (run) {
-      st = fast_light(M, P, S, F, be, M.w0 + KF_W);
-      done = st == kFastDone;
+    // 1. to the next event; 2. flush, and what the event needs.  A lane whose event needs nothing
+    // from far memory (typically a flush whose probe bytes were kept when the match was found)
+    // goes on to its next event in the same round.
+    bool ev = false, needw = false, go = !done && !rare;
+#pragma unroll 1
+    for (int pass = 0; pass < KF_PASSES; pass++) {
+      if (go) {
+        const int st = fast_light(M, P, S, F, be, M.w0 + KF_W);
+        done = st == kFastDone;
+        needw = st == kFastWindow;
+        ev = st == kFastEvent;
+        go = false;
+        if (ev) {
+          const bool inw = (uint32_t)(S.i - M.w0) < (uint32_t)KF_W;
+          go = fast_issue(M, len_eff, P, S, F, sink, inw, M.w0);
+          needw = !inw;
+          rare = F.rare != 0;
+          ev = !go;
+        }
+      }
+      if (__ballot(go) == 0) break;
     }
-    const bool ev = run && st == kFastEvent;
-    bool needw = run && st == kFastWindow;
-    // 2. flush, and what the event needs
-    if (ev) {
-      const bool inw = (uint32_t)(S.i - M.w0) < (uint32_t)KF_W;
-      fast_issue(M, len_eff, P, S, F, sink, inw, M.w0);
-      needw = !inw;
-      rare = F.rare != 0;
-    }
+    // (a lane still free after the last pass has nothing outstanding: it simply runs again next round)
     if (__ballot(!done) == 0) break;
 
     // 3. loads: windows (the rows take turns when more than KF_MAX_ROWS ask) ...
+    const bool lc = ev && F.ld_cand >= 0;
     const unsigned long long wmask = __ballot(needw);
     uint4 rv[KF_ITERS];
     int npieces = 0;
@@ -1004,11 +1018,12 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
       }
     }
     // ... and the events' far bytes
-    const bool lp = ev && F.ld_probe >= 0, lc = ev && F.ld_cand >= 0;
+    const bool lp = ev && F.ld_probe >= 0;
     const uint64_t pl = M.far64(lp ? F.ld_probe : 0);
     const uint64_t cb = M.far64(lc ? F.ld_cand - 8 : 0);
     const uint64_t cf = M.far64(lc ? F.ld_cand : 0);
     const uint64_t cf2 = M.far64(lc ? F.ld_cand + 8 : 0);
+    const uint64_t cf3 = M.far64(lc ? F.ld_cand + 16 : 0);
 
     if (wmask) {
 #pragma unroll
@@ -1033,7 +1048,7 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
     }
     // 4. the rest of the event's iteration
     if (ev && !rare) {
-      fast_complete(M, len_eff, P, S, F, (uint32_t)(S.i - M.w0) < (uint32_t)KF_W, pl, cb, cf, cf2);
+      fast_complete(M, len_eff, P, S, F, (uint32_t)(S.i - M.w0) < (uint32_t)KF_W, pl, cb, cf, cf2, cf3);
       rare = F.rare != 0;
       if (len_eff < len && (S.error & kStateTouchedEnd)) aborted = done = true, rare = false;
     }

@@ -13,8 +13,9 @@
 //                  bytes; the table entries through a bit mask made when the window was filled) --
 //                  and stop at the first position with an event: a flush is due (m4.go:113), the
 //                  table entry may match (m4.go:152-159), the probe hits or needs bytes.
-//   fast_issue     at the event: flush (state only), then say which far bytes the rest of the
-//                  iteration needs: 8 bytes for the probe, 24 around the candidate.
+//   fast_issue     at the event: flush (state only), the probe at this position if its bytes are
+//                  cached, then say which far bytes the rest of the iteration needs: 8 bytes for
+//                  the probe, 32 around the candidate.
 //   fast_complete  with those bytes: probe, candidate evaluation (extendMatch2 within the 24
 //                  bytes), score test, push (m4.go:159-209).
 //
@@ -86,7 +87,7 @@ M4G_HD int fast_light(const Mem &M, const ParseParams &P, ParseState &S, const F
   const int32_t i = S.i, e0 = S.m0.end;
   const bool pend = e0 != 0, interior = pend && i < e0;
   const int32_t lim_pos = be < wend ? be : wend;
-  const bool here = i < lim_pos; // position i is inside the range and the window
+  const bool here = i < lim_pos && i >= wend - KF_W; // position i is inside the range and the window
   const int32_t ii = here ? i : wend - 1;
   const int st_out = i >= be ? kFastDone : kFastWindow; // when not here
   // the one searched position inside a pending match (m4.go:149-151)
@@ -120,43 +121,65 @@ M4G_HD int fast_light(const Mem &M, const ParseParams &P, ParseState &S, const F
   return st;
 }
 
-// The event at S.i, part 1.  in_window: S.i lies in the window (a flush can be due beyond it).
+// The event at S.i, part 1: flush, the repeat probe on cached bytes, and which far bytes the rest
+// of the iteration needs.  in_window: S.i lies in the window (a flush can be due beyond it; then
+// only the flush is done here and the position is looked at again once the window is there).
+// Returns true when nothing is left to do at this position (no bytes wanted, not rare): the caller
+// may go straight on with fast_light.
 template <class Mem, class Sink>
-M4G_HD void fast_issue(const Mem &M, int32_t len, const ParseParams &P, ParseState &S, FastLane &F, Sink &sink,
+M4G_HD bool fast_issue(const Mem &M, int32_t len, const ParseParams &P, ParseState &S, FastLane &F, Sink &sink,
                        bool in_window, int32_t w0) {
   const int32_t i = S.i;
   if (S.m0.end != 0 && i >= S.m0.end) flush(S, P, sink); // m4.go:113-126
   const bool probing = S.m0.end == 0 && S.have_prev;
   const int32_t c = i + 1 - (int32_t)S.prev_dist;
+  const uint32_t off = (uint32_t)(c - F.pc_base);
   // c < 0: the Go code would panic on the slice bounds; parse_range records it
   bool rare = probing && c < 0;
-  F.ld_probe = probing && c >= 0 && (uint32_t)(c - F.pc_base) > 4 ? c : -1; // (c + 8 <= len: c <= i <= len - 8)
-  const uint32_t ce = M.near_chain(in_window ? i : w0);
+  const bool want_probe = probing && c >= 0 && off > 4; // (c + 8 <= len: c <= i <= len - 8)
+  // m4.go:128-138 on the cached bytes: a hit is for parse_range
+  const int32_t ii = in_window ? i : w0;
+  const bool hit = probing && in_window && off <= 4 && (uint32_t)(F.pc >> (8 * (off & 7))) == M.near32(ii + 1);
+  rare = rare || hit;
+  const uint32_t ce = M.near_chain(ii);
   const bool hv = in_window && fast_heavy(ce, P);
   const int32_t cand = i - (int32_t)(ce & kChainDelta);
-  const bool edge = cand < 8 || i + 16 > len; // the ends of the buffer
+  const bool edge = cand < 8 || i + 24 > len; // the ends of the buffer
   rare = rare || (hv && edge);
+  F.ld_probe = want_probe && !rare ? c : -1;
   F.ld_cand = hv && !rare ? cand : -1;
-  if (rare) F.ld_probe = -1;
   F.rare = rare;
+  return in_window && !rare && !want_probe && !hv;
 }
 
-// The event at S.i, part 2.  pl = the 8 bytes at F.ld_probe; cb / cf / cf2 = the 8 bytes at
-// F.ld_cand - 8 / + 0 / + 8 (each only if asked for).  in_window as above: without the window
-// only the probe bytes are kept.
+// 8 bytes from byte offset o (5..16) of the 24 bytes q0..q5 (little-endian dwords)
+M4G_HD uint64_t bytes_at(uint64_t a, uint64_t b, uint64_t c, uint32_t o) {
+  const uint32_t q[7] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32),
+                         (uint32_t)c, (uint32_t)(c >> 32), 0u};
+  const uint32_t j = o >> 2, sh = 8 * (o & 3);
+  uint32_t d0 = q[1], d1 = q[2], d2 = q[3];
+  if (j == 2) d0 = q[2], d1 = q[3], d2 = q[4];
+  if (j == 3) d0 = q[3], d1 = q[4], d2 = q[5];
+  if (j == 4) d0 = q[4], d1 = q[5], d2 = q[6];
+  const uint64_t lo = ((uint64_t)d1 << 32) | d0, hi = ((uint64_t)d2 << 32) | d1;
+  return (uint64_t)(uint32_t)(lo >> sh) | ((uint64_t)(uint32_t)(hi >> sh) << 32);
+}
+
+// The event at S.i, part 2.  pl = the 8 bytes at F.ld_probe; cb / cf / cf2 / cf3 = the 8 bytes at
+// F.ld_cand - 8 / + 0 / + 8 / + 16 (each only if asked for).  in_window as above: without the
+// window only the probe bytes are kept.
 template <class Mem>
 M4G_HD void fast_complete(const Mem &M, int32_t len, const ParseParams &P, ParseState &S, FastLane &F, bool in_window,
-                          uint64_t pl, uint64_t cb, uint64_t cf, uint64_t cf2) {
-  if (F.ld_probe >= 0) {
+                          uint64_t pl, uint64_t cb, uint64_t cf, uint64_t cf2, uint64_t cf3) {
+  const bool fresh = F.ld_probe >= 0;
+  if (fresh) {
     F.pc = pl;
     F.pc_base = F.ld_probe;
   }
   if (!in_window) return;
   const int32_t i = S.i;
-  // m4.go:128-138 at this position: a hit is for parse_range
-  const uint32_t off = (uint32_t)(i + 1 - (int32_t)S.prev_dist - F.pc_base); // <= 4 by now when probing
-  const bool probe_hit = S.m0.end == 0 && S.have_prev && (uint32_t)(F.pc >> (8 * (off & 7))) == M.near32(i + 1);
-  if (probe_hit) {
+  // m4.go:128-138 at this position on the bytes that just came: a hit is for parse_range
+  if (fresh && (uint32_t)pl == M.near32(i + 1)) {
     F.rare = 1;
     return;
   }
@@ -196,6 +219,10 @@ M4G_HD void fast_complete(const Mem &M, int32_t len, const ParseParams &P, Parse
     S.m1 = S.m0;
     S.m0 = cur;
     if (S.first_i < 0) S.first_i = i;
+    // When this match is flushed, the repeat probe (m4.go:128-138) starts one byte behind its
+    // source: those bytes are among the ones just read (the match ends at most 15 bytes above i).
+    F.pc_base = cand + (end - i) + 1;
+    F.pc = bytes_at(cf, cf2, cf3, (uint32_t)(end - i + 1));
   }
   S.i = next_pos(S, P, i);
 }

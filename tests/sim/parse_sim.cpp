@@ -68,13 +68,15 @@ bool fast_lane_parse(const uint8_t *src, const uint32_t *chain, int32_t n, int32
       continue;
     }
     const bool inw = (uint32_t)(S.i - M.w0) < (uint32_t)KF_W;
-    fast_issue(M, len_eff, P, S, F, sink, inw, S.i);
-    uint64_t pl = 0, cb = 0, cf = 0, cf2 = 0;
-    if (!F.rare && F.ld_probe >= 0) pl = ld64(src + F.ld_probe);
-    if (!F.rare && F.ld_cand >= 0) cb = ld64(src + F.ld_cand - 8), cf = ld64(src + F.ld_cand), cf2 = ld64(src + F.ld_cand + 8);
+    const bool free_ = fast_issue(M, len_eff, P, S, F, sink, inw, S.i);
+    if (free_) continue; // (the device runs fast_light a second time in the same round)
+    uint64_t pl = 0, cb = 0, cf = 0, cf2 = 0, cf3 = 0;
+    if (F.ld_probe >= 0) pl = ld64(src + F.ld_probe);
+    if (F.ld_cand >= 0)
+      cb = ld64(src + F.ld_cand - 8), cf = ld64(src + F.ld_cand), cf2 = ld64(src + F.ld_cand + 8), cf3 = ld64(src + F.ld_cand + 16);
     if (!inw) M.w0 = S.i & ~(KF_W - 1); // (the device may serve the window a round later: in_window = false then)
-    if (!F.rare) fast_complete(M, len_eff, P, S, F, inw, pl, cb, cf, cf2);
-    if (F.rare) parse_range<false, false>(G, len_eff, P, S, S.i + 1, sink);
+    if (!F.rare) fast_complete(M, len_eff, P, S, F, inw, pl, cb, cf, cf2, cf3);
+    if (F.rare) parse_range<false, false, false, false>(G, len_eff, P, S, S.i + 1, sink);
     if (len_eff < n && (S.error & kStateTouchedEnd)) return false;
   }
 }

@@ -90,6 +90,32 @@ def test_writer_edge_streams(fmt, kw):
             assert got == want, (len(data), bs)
 
 
+@pytest.mark.parametrize("fmt,kw", FORMATS[::2] + FORMATS[3:], ids=["brotli-G", "flate5", "gzip7"])
+def test_writer_block_size_0_empty_write_and_kept_output(fmt, kw):
+    """BlockSize 0: every Write is one block (matchfinder.go:64-66), an empty one included; and a Write whose
+    output exceeds the wrapper's 1 MiB buffer goes through the kept-output retry (a call with n = 0)."""
+    from oracle_lib import OracleEncoder, OracleFlateEncoder
+    rng = np.random.default_rng(12)
+    noise = bytes(rng.integers(0, 256, 1_300_000, dtype=np.uint8))  # incompressible: > 1 MiB of output
+    text = synth.text(200000, 5)
+    writes = [text[:70000], b"", noise, b"", text[70000:]]
+    mf = OracleM4(**kw)
+    enc = OracleEncoder() if fmt == m4.FORMAT_BROTLI else OracleFlateEncoder(gzip=fmt == m4.FORMAT_GZIP, mtime=77)
+    want = b""
+    for p in writes:
+        want += enc.Encode(p, mf.FindMatches(p), False)
+    want += enc.Encode(b"", mf.FindMatches(b""), True)
+    dest = io.BytesIO()
+    w = m4.GPUWriter(dest, fmt, 0, mtime=77, **kw)
+    for p in writes:
+        w.Write(p)
+    w.Close()
+    got = dest.getvalue()
+    data = b"".join(writes)
+    assert decode(fmt, got, len(data)) == data
+    assert got == want
+
+
 def test_writer_large_stream_and_small_output_buffer():
     """32 MiB through the one-launch path in two Writes (flate: the 32 KiB window slides at every block); the
     Python wrapper starts with a 1 MiB output buffer, so the kept-output / retry protocol is exercised too."""
