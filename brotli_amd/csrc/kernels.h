@@ -951,6 +951,8 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
   uint32_t round = 0;
 #ifdef M4G_KF_STATS
   uint32_t n_rare = 0, n_fill = 0; // rounds that ran the parked batch / filled windows
+  uint64_t t_rare = 0;
+  const uint64_t t_begin = wall_clock64();
 #endif
 
   for (;;) {
@@ -1057,17 +1059,24 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
     if (__builtin_expect(rmask && (__builtin_popcountll(rmask) >= KF_RARE_BATCH || __ballot(!done && !rare) == 0), 0)) {
 #ifdef M4G_KF_STATS
       n_rare++;
+      const uint64_t tr0 = wall_clock64();
 #endif
       if (rare) {
         parse_range<false, false, false, false>(M, len_eff, P, S, S.i + 1, sink);
         rare = false;
         if (len_eff < len && (S.error & kStateTouchedEnd)) aborted = done = true;
       }
+#ifdef M4G_KF_STATS
+      t_rare += wall_clock64() - tr0;
+#endif
     }
     round++;
   }
 #ifdef M4G_KF_STATS
-  if (lane == 0) atomicAdd(errors + 13, round), atomicAdd(errors + 14, n_rare), atomicAdd(errors + 15, n_fill);
+  if (lane == 0) {
+    atomicAdd(errors + 13, round), atomicAdd(errors + 14, n_rare), atomicAdd(errors + 15, n_fill);
+    atomicAdd(errors + 9, (uint32_t)((wall_clock64() - t_begin) >> 8)), atomicAdd(errors + 10, (uint32_t)(t_rare >> 8)); // 100 MHz ticks / 256
+  }
 #endif
   if (!active) return;
   if (aborted) {

@@ -695,7 +695,8 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
                  w[4], w[5], w[6], w[7]);
     if (w[13]) // builds with M4G_KF_STATS: k3a_fast's rounds, summed over its waves
       std::fprintf(stderr, "[m4g] k3a_fast: %u wave-rounds, %u of them ran the parked batch, %u filled windows\n", w[13], w[14], w[15]);
-    if (w[9] | w[10] | w[11] | w[12]) // builds with M4G_K3C_TIMING: wave time per path, summed over the chunks
+    if (w[13] && w[9]) std::fprintf(stderr, "[m4g] k3a_fast wave-ms: total %.2f, parked batches %.2f\n", w[9] * 256 / 1e5, w[10] * 256 / 1e5);
+    else if (w[9] | w[10] | w[11] | w[12]) // builds with M4G_K3C_TIMING: wave time per path, summed over the chunks
       std::fprintf(stderr, "[m4g] k3c wave-ms: scan %.2f, covered skip %.2f, probe check %.2f, serial %.2f\n",
                    w[9] * 16 / 1e5, w[10] * 16 / 1e5, w[11] * 16 / 1e5, w[12] * 16 / 1e5);
   }
@@ -1306,6 +1307,16 @@ int na_scratch_ptr(int device, unsigned char **out) {
 }
 } // namespace
 
+// Test hook: fill this device's copy of the scratch array with `value` (no allocation: a memset on the symbol's
+// address), so that a test can show that a call reads nothing an earlier call left behind.
+extern "C" int m4g_debug_noalloc_poison(int device, int value, void *hip_stream) {
+  HIP_TRY(hipSetDevice(device));
+  unsigned char *base = nullptr;
+  if (int rc = na_scratch_ptr(device, &base)) return rc;
+  HIP_TRY(hipMemsetAsync(base, value, NA_SCRATCH_BYTES, static_cast<hipStream_t>(hip_stream)));
+  return M4G_OK;
+}
+
 extern "C" int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uint8_t *d_src,
                                             const uint64_t *chunk_off, size_t nchunks, m4g_match *d_out,
                                             uint64_t *d_out_off, size_t out_cap, m4g_histo *d_histos,
@@ -1727,7 +1738,7 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
   out_off[nchunks] = run;
   if (run > out_cap) {
     cleanup();
-    return -(int64_t)run;
+    return -(int64_t)(run + M4G_STREAM_NEEDED_BIAS); // (counts above 10^6 are routine here: out of the M4G_ERR_* range)
   }
 
   // 3. ordered concatenation on the host: each chunk's list lands at out_off[c]
@@ -2069,7 +2080,7 @@ extern "C" int64_t m4g_hostbatch_run(m4g_hostbatch *h, const uint8_t *base, cons
     run += L.count_off[k + 1] - L.count_off[k];
   }
   out_off[nchunks] = run;
-  if (run > out_cap) return -(int64_t)run;
+  if (run > out_cap) return -(int64_t)(run + M4G_STREAM_NEEDED_BIAS);
   {
     std::vector<std::thread> th;
     for (size_t g = 1; g < ndev; g++) th.emplace_back(hostlane_phase2, h, std::ref(h->lanes[g]), out_off, out, histos);

@@ -44,7 +44,7 @@ EXPORTS = [
     "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_batch_run_device_codes",
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
-    "m4g_batch_status", "m4g_batch_run_device_noalloc",
+    "m4g_batch_status", "m4g_batch_run_device_noalloc", "m4g_debug_noalloc_poison",
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
     "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
     "m4g_bargain_create", "m4g_bargain_destroy", "m4g_bargain_block_count", "m4g_bargain_run_device",
@@ -134,6 +134,7 @@ def lib():
         L.m4g_writer_destroy.argtypes = [vp]
         L.m4g_writer_destroy.restype = None
         L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
+        L.m4g_debug_noalloc_poison.argtypes = [ctypes.c_int, ctypes.c_int, vp]
         L.m4g_bargain_create.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, sz, sz, sz, ctypes.POINTER(vp)]
         L.m4g_bargain_destroy.argtypes = [vp]
         L.m4g_bargain_destroy.restype = None
@@ -667,6 +668,11 @@ def flate_m4_params(level: int) -> dict:
     return dict(MaxDistance=1 << 15, ChainLength={5: 8, 6: 16, 7: 32}[level], HashLen=5, DistanceBitCost=66)
 
 
+def noalloc_poison(value: int = 0xFF, device: int = 0, stream: int = 0):
+    """Test hook: fill the no-alloc entry point's scratch array on `device` with a byte value."""
+    _check(lib().m4g_debug_noalloc_poison(device, value, stream), "m4g_debug_noalloc_poison")
+
+
 def run_device_noalloc(d_src, chunk_off: np.ndarray, d_out, d_out_off, d_histos=None, stream: int = 0,
                        device: int = 0, **m4_fields):
     """m4g_batch_run_device_noalloc: BatchPlan.run without a plan -- the workspace
@@ -751,7 +757,7 @@ class HostBatch:
                                     out_off.ctypes.data, cap, histos.ctypes.data if want_histos else None)
         _check(r, "m4g_hostbatch_run")
         if r < 0:
-            raise M4GError(f"m4g_hostbatch_run: out_cap too small, need {-r}")
+            raise M4GError(f"m4g_hostbatch_run: out_cap too small, need {-r - STREAM_NEEDED_BIAS}")
         return out[:int(out_off[n])], out_off, (histos[:n] if want_histos else None)
 
 
@@ -800,6 +806,6 @@ def find_matches_batch(base, chunk_off: Sequence[int], devices: Sequence[int] = 
                                      histos.ctypes.data if want_histos else None)
     _check(r, "m4g_find_matches_batch")
     if r < 0:
-        raise M4GError(f"m4g_find_matches_batch: out_cap too small, need {-r}")
+        raise M4GError(f"m4g_find_matches_batch: out_cap too small, need {-r - STREAM_NEEDED_BIAS}")
     total = int(out_off[n])
     return out[:total], out_off, (histos[:n] if want_histos else None)

@@ -90,10 +90,11 @@ enum {
   M4G_ERR_INTERNAL = -1000007      /* a kernel-side capacity check failed; the
                                       output of that call is not valid */
 };
-/* Count-returning entry points use values >= -1000000 for "-(needed)"; the
- * stream encoders (m4g_batch_encode, m4g_batch_flate_encode), whose outputs
- * can be far larger, return -(needed + M4G_STREAM_NEEDED_BIAS) instead, which
- * is below every M4G_ERR_* value. */
+/* Count-returning entry points of ONE block use values >= -1000000 for
+ * "-(needed)"; the entry points whose outputs can be far larger -- the stream
+ * encoders and the batch calls over host memory (m4g_find_matches_batch,
+ * m4g_hostbatch_run) -- return -(needed + M4G_STREAM_NEEDED_BIAS) instead,
+ * which is below every M4G_ERR_* value. */
 #define M4G_STREAM_NEEDED_BIAS 2000000
 
 /* Human-readable text for an error code. */
@@ -207,8 +208,9 @@ int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src,
 /* Host-memory form over one or more devices: chunk c goes to
  * devices[c % ndevices]; per-chunk Match lists and histograms come back over
  * pinned async copies and are concatenated in chunk order on the host.
- * No inter-GPU communication.  Returns M4G_OK, or -(needed) when out_cap is
- * too small, or an M4G_ERR_*. */
+ * No inter-GPU communication.  Returns M4G_OK, or -(needed +
+ * M4G_STREAM_NEEDED_BIAS) when out_cap is too small (out_off[nchunks] holds
+ * the count as well), or an M4G_ERR_*. */
 int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_t *base,
                                const uint64_t *chunk_off, size_t nchunks,
                                const int *devices, int ndevices, m4g_match *out,
@@ -365,9 +367,16 @@ int64_t m4g_flate_encode_blocks(int device, const uint8_t *src, size_t n, size_t
  * full block, keeps the rest (lines 59-79); m4g_writer_close = Writer.Close: the
  * remainder, possibly empty, as the last block (lines 89-93); m4g_writer_reset
  * = Writer.Reset (lines 95-103).  Where the reference hands bytes to Dest.Write,
- * these calls return them in `out`: exactly the bytes the reference's Writer has
- * written after the same sequence of calls (whole bytes; the encoder's pending
- * bits stay inside, bitwriter.go:11-17).  A call whose blocks qualify for the
+ * these calls return them in `out`.  The CONCATENATION of what the calls return,
+ * Close included, is the reference Writer's output for the same sequence of
+ * calls.  brotli: every call also returns exactly what the reference has written
+ * by then (whole bytes; fewer than 8 pending bits stay inside, bitwriter.go).
+ * flate / gzip: the split between calls can differ by up to 5 bytes -- the
+ * reference's huffmanBitWriter hands bytes on in groups of 6 once 48 bits are
+ * pending (flate/huffman_bit_writer.go:110-126), this one keeps fewer than 8
+ * bits.  With BlockSize 0 an empty Write is a block too (flate: an empty stored
+ * or fixed block), EXCEPT when output of the previous call is still kept: then
+ * n = 0 only fetches it (the retry below).  A call whose blocks qualify for the
  * one-launch path of m4g_find_matches_blocks (two or more blocks of >= 3847
  * bytes) finds the matches and encodes without moving Match lists or bytes over
  * PCIe a second time.  If out_cap is too small the call returns -(needed +
@@ -432,6 +441,9 @@ int m4g_batch_run_device_noalloc(const m4g_params *params, int device, const uin
                                  const uint64_t *chunk_off, size_t nchunks,
                                  m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
                                  m4g_histo *d_histos, void *hip_stream);
+/* Test hook for the entry point above: fills this device's copy of the scratch
+ * array with `value` (a memset on the symbol's address, no allocation). */
+int m4g_debug_noalloc_poison(int device, int value, void *hip_stream);
 
 /* ---- matchfinder.Bargain1 / Bargain2 / Bargain3 -------------
  * The shortest-path match finders that brotli.NewWriterV2 plugs into

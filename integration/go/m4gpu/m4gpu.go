@@ -21,6 +21,7 @@ package m4gpu
 import "C"
 
 import (
+	"fmt"
 	"io"
 	"runtime"
 	"unsafe"
@@ -185,6 +186,9 @@ func (q *M4) Batch(data []byte, chunkOff []uint64, devices []int, wantHistos boo
 	}
 	rc := C.m4g_find_matches_batch(&p, dp, (*C.uint64_t)(unsafe.Pointer(&chunkOff[0])), C.size_t(nchunks),
 		&devs[0], C.int(len(devs)), &out[0], (*C.uint64_t)(unsafe.Pointer(&outOff[0])), C.size_t(len(out)), hp)
+	if rc < -C.M4G_STREAM_NEEDED_BIAS { // cannot happen with the worst-case capacity above; the count is -(rc + bias)
+		panic(fmt.Sprintf("m4gpu: m4g_find_matches_batch: out too small, %d matches", -int64(rc)-C.M4G_STREAM_NEEDED_BIAS))
+	}
 	if rc != 0 {
 		fail("m4g_find_matches_batch", C.int(rc))
 	}

@@ -31,6 +31,9 @@ def _both(host, sizes, kw):
             plan.run(d_src, off, d_out, d_off, d_h)
             plan.status()
         else:
+            # whatever an earlier call left in the shared array is gone: 0xFF in every byte (counts, states,
+            # descriptors, chain entries of sub-blocks beyond a shorter chunk would all be wildly wrong if read)
+            m4.noalloc_poison(0xFF)
             m4.run_device_noalloc(d_src, off, d_out, d_off, d_h, **kw)
         torch.cuda.synchronize()
         o = d_off.cpu().numpy()
