@@ -236,8 +236,27 @@ __global__ __launch_bounds__(64, 8) void kb_parse(
   float *gC = ws_cost + (size_t)blockIdx.x * ws_stride;
 
   // (the grid is what the GPU holds at once, bargain_host.h; blocks are equally long but for the last of a stream)
+#ifdef M4G_KB_HANDOUT
+  // Variant: blocks handed out through a counter (the word behind the counts, zeroed by the host on this stream
+  // before the launch).  ONE lane fetches the index and it is broadcast through a scalar register, so the loop
+  // test below is wave-uniform (DESIGN 3.6 has the ISA and what a per-lane index does to this loop).
+  uint32_t *next_block = counts + nblocks;
+#pragma unroll 1
+  for (;;) {
+#ifdef M4G_KB_HANDOUT_BRANCHY /* the form that never returns: DESIGN 3.6 */
+    uint32_t bv = 0;
+    if (lane == 0) bv = atomicAdd(next_block, 1u);
+#else
+    // every lane takes part in the fetch (lane 0 adds 1, the others 0): no `if (lane == 0)` here for the
+    // compiler to merge with the one that ends the body
+    const uint32_t bv = atomicAdd(next_block, lane == 0 ? 1u : 0u);
+#endif
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv);
+    if (b >= nblocks) break;
+#else
 #pragma unroll 1
   for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+#endif
     const BBlock B = blocks[b];
     const Job J = jobs[B.job];
     const uint8_t *src = src_base + J.src_off;

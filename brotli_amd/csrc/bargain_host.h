@@ -148,7 +148,7 @@ extern "C" int m4g_bargain_create(const m4g_bargain_params *params, int device, 
   dev(&g->d_k1jobs, g->max_k1jobs * sizeof(Job));
   dev(&g->d_blocks, g->max_blocks * sizeof(BBlock));
   dev(&g->d_chain, g->chain_words * 4 * (size_t)d.nt);
-  dev(&g->d_counts, g->max_blocks * 4);
+  dev(&g->d_counts, (g->max_blocks + 1) * 4); // (+1: the hand-out counter of the M4G_KB_HANDOUT variant)
   dev(&g->d_bc, g->max_blocks * 256 * sizeof(float));
   dev(&g->d_wc, (size_t)g->nwaves * g->ws_stride * sizeof(float));
   dev(&g->d_wld, (size_t)g->nwaves * g->ws_stride * sizeof(uint2));
@@ -267,6 +267,9 @@ int64_t bargain_run_impl(m4g_bargain *g, const uint8_t *d_src, const uint64_t *c
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(g->ev[2], st));
   const unsigned grid = (unsigned)std::min<size_t>(nb, g->nwaves);
+#ifdef M4G_KB_HANDOUT
+  HIP_TRY(hipMemsetAsync(g->d_counts + nb, 0, 4, st)); // the hand-out counter, on the kernels' stream
+#endif
   if (g->d.nt == 1)
     hipLaunchKernelGGL(kb_parse<1>, dim3(grid), dim3(64), 0, st, d_src, src_total, g->d_chain, g->d_jobs, g->d_blocks,
                        (uint32_t)nb, g->d_bc, g->d_wld, g->d_wc, g->ws_stride, g->d_stage, g->stage_cap, g->d_counts, g->d.P);
