@@ -2455,8 +2455,17 @@ bool blocks_one_launch_ok(const Params &p, size_t n, size_t block_size) {
   const size_t nblocks = (n + block_size - 1) / block_size;
   return nblocks >= 2 && block_size >= (size_t)kK1MaxTile + 7 && (uint64_t)p.max_distance >= (uint64_t)kK1MaxTile;
 }
+// Span mode (one stream over several devices, m4g_find_matches_blocks_multi): `src` holds the stream from a block
+// boundary at or below the origin in force for the first wanted block; the blocks from byte `skip` on are wanted,
+// the bytes before only stand for the history a sequential run would hold.  org[b]: the origin of wanted block b
+// (m4.go:82-99 replayed over the WHOLE stream by the caller), in coordinates of `src`.  The handle must be fresh
+// (no history) and stays so.
+struct SpanMode {
+  size_t skip;
+  const uint64_t *org;
+};
 int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_size, m4g_match *out, size_t out_cap,
-                         uint64_t *block_off, BlocksHook *hook);
+                         uint64_t *block_off, BlocksHook *hook, const SpanMode *sm = nullptr);
 } // namespace
 
 extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_size,
@@ -2466,16 +2475,19 @@ extern "C" int64_t m4g_find_matches_blocks(m4g_ctx *c, const uint8_t *src, size_
 
 namespace {
 int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_size, m4g_match *out, size_t out_cap,
-                         uint64_t *block_off, BlocksHook *hook) {
+                         uint64_t *block_off, BlocksHook *hook, const SpanMode *sm) {
   if (!c || (!src && n) || (!out && out_cap) || block_size == 0)
     return fail(M4G_ERR_BAD_PARAM, "NULL argument or block_size 0");
   const Params &p = c->p;
   if ((uint64_t)c->hist_len + n >= ((uint64_t)1 << 31))
     return fail(M4G_ERR_TOO_LARGE, "history + data must stay below 2^31 bytes");
-  const size_t nblocks = (n + block_size - 1) / block_size;
+  const size_t skip = sm ? sm->skip : 0; // bytes of `src` that are history only
+  if (sm && (c->hist_len != 0 || hook || skip % block_size != 0 || skip >= n))
+    return fail(M4G_ERR_INTERNAL, "span mode: fresh handle, whole blocks, no hook");
+  const size_t nblocks = (n - skip + block_size - 1) / block_size;
   size_t need = 0;
   for (size_t b = 0; b < nblocks; b++)
-    need += std::min(block_size, n - b * block_size) / (size_t)p.min_length + 2;
+    need += std::min(block_size, n - skip - b * block_size) / (size_t)p.min_length + 2;
   if (out_cap < need && n != 0 && !hook) {
     g_last_error = "out_cap below the sum of len/min_length + 2 over the blocks";
     return -(int64_t)need;
@@ -2487,8 +2499,9 @@ int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_
   // The one-launch path needs: more than one block, at most one block end and
   // one slide per K1 tile, and a bounded slide list.  Otherwise: block by block.
   const uint64_t W = (uint64_t)p.max_distance;
-  const bool shape_ok = nblocks >= 2 && block_size >= (size_t)kK1MaxTile + 7 && W >= (uint64_t)kK1MaxTile;
-  if (shape_ok && (n / W + 2 >= (size_t)kStreamMaxSlides || nblocks >= ((size_t)1 << 24))) {
+  const bool shape_ok = (nblocks >= 2 || sm) && block_size >= (size_t)kK1MaxTile + 7 && W >= (uint64_t)kK1MaxTile;
+  if (sm && !shape_ok) return fail(M4G_ERR_INTERNAL, "span mode needs the one-launch shape");
+  if (!sm && shape_ok && (n / W + 2 >= (size_t)kStreamMaxSlides || nblocks >= ((size_t)1 << 24))) {
     // more history slides than one launch's list holds (a small MaxDistance: flate's 32 KiB window slides at
     // every block): spans of whole blocks, each one launch; the handle carries the state from span to span
     const size_t span_blocks = std::max<size_t>(2, std::min<size_t>(((size_t)kStreamMaxSlides - 3) * W / block_size,
@@ -2523,24 +2536,26 @@ int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_
   HIP_TRY(hipSetDevice(c->device));
   int rc = ctx_slide(c);
   if (rc) return rc;
-  const uint64_t x0 = (uint64_t)c->hist_len, x_end = x0 + n;
+  const uint64_t x0 = sm ? (uint64_t)skip : (uint64_t)c->hist_len, x_end = sm ? (uint64_t)n : x0 + n;
   if ((rc = ctx_reserve(c, (size_t)x_end))) return rc;
 
   // slide schedule of the equivalent call sequence (m4.go:82-99)
   StreamInfo si{};
-  si.x0 = (uint32_t)x0;
+  si.x0 = sm ? 0u : (uint32_t)x0; // (span mode: the buffer begins at a block boundary of the stream)
   si.x_end = (uint32_t)x_end;
   si.block_size = (uint32_t)block_size;
   si.nbp = 1;
   si.bp_x[0] = 0;
-  si.bp_org[0] = 0;
-  uint64_t org = 0;
+  si.bp_org[0] = sm ? (uint32_t)sm->org[0] : 0u;
+  uint64_t org = sm ? sm->org[0] : 0;
   std::vector<Job> jobs; // segments first, then blocks
   std::vector<uint64_t> block_org(nblocks);
   for (size_t b = 0; b < nblocks; b++) {
     const uint64_t xb = x0 + b * block_size;
-    if (b > 0 && xb - org > 2 * W) { // len(history) > 2*MaxDistance at the start of this call
-      org = xb - W;
+    const bool moved = sm ? sm->org[b] != org : (b > 0 && xb - org > 2 * W); // len(history) > 2*MaxDistance at the start of this call
+    if (moved) {
+      org = sm ? sm->org[b] : xb - W;
+      if (si.nbp >= (uint32_t)kStreamMaxSlides) return fail(M4G_ERR_INTERNAL, "more history slides than one launch's list holds");
       si.bp_x[si.nbp] = (uint32_t)xb;
       si.bp_org[si.nbp] = (uint32_t)org;
       si.nbp++;
@@ -2552,17 +2567,22 @@ int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_
   // K1 segments: the first one continues the handle's table and covers at
   // least MaxDistance bytes, so every later segment primes from this call's data
   const uint64_t S = std::max<uint64_t>(256u << 10, std::min<uint64_t>(4u << 20, (n + 63) / 64));
-  uint64_t a = x0;
+  // Span mode: no table to continue.  The first segment starts MaxDistance below the first wanted block with an
+  // empty table and STORES from there: chain entries of the history are read by chain walks (m4.go:166-181,
+  // 239-252), and only those of positions within MaxDistance of a wanted position can be reached; a predecessor
+  // further back than that is rejected by the distance test wherever it is read, so "none" stands for it.
+  const uint64_t first = sm ? (x0 > W ? x0 - W : 0) : x0;
+  uint64_t a = first;
   while (a < x_end) {
-    uint64_t e = a == x0 ? std::min(x_end, x0 + std::max(W, S)) : std::min(x_end, a + S);
+    uint64_t e = a == first ? std::min(x_end, std::max(x0, first) + std::max(W, S)) : std::min(x_end, a + S);
     if (x_end - e < S / 4) e = x_end; // no tiny tail segment
     Job J{};
     J.src_off = 0;
     J.chain_off = 0;
-    J.start = (uint32_t)(a == x0 ? x0 : a - W);
+    J.start = (uint32_t)(a == first ? first : a - W);
     J.len = (uint32_t)(e + 7); // K1 inserts positions below len - 7 (block ends are skipped by rule)
     J.store_from = (uint32_t)a;
-    J.k1_flags = (a == x0 ? kJobLoadTable : 0u) | (e == x_end ? kJobStoreTable : 0u);
+    J.k1_flags = (a == first && !sm ? kJobLoadTable : 0u) | (e == x_end ? kJobStoreTable : 0u);
     jobs.push_back(J);
     a = e;
   }
@@ -2620,8 +2640,8 @@ int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_
 
   Trace tr;
   // m4.go:101-107: append src; chain entries of never-inserted positions stay 0
-  HIP_TRY(hipMemcpyAsync(c->d_hist + x0, src, n, hipMemcpyHostToDevice, c->st));
-  HIP_TRY(hipMemsetAsync(c->d_chain + x0, 0, n * 4, c->st));
+  HIP_TRY(hipMemcpyAsync(c->d_hist + (sm ? 0 : x0), src, n, hipMemcpyHostToDevice, c->st));
+  HIP_TRY(hipMemsetAsync(c->d_chain + first, 0, (x_end - first) * 4, c->st));
   HIP_TRY(hipMemcpyAsync(c->d_bjobs, jobs.data(), jobs.size() * sizeof(Job), hipMemcpyHostToDevice, c->st));
   HIP_TRY(hipMemcpyAsync(c->d_si, &si, sizeof(si), hipMemcpyHostToDevice, c->st));
   HIP_TRY(hipMemsetAsync(c->d_counts, 0, 8, c->st));
@@ -2650,14 +2670,15 @@ int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_
     if (int rce = status_from_error_word(c->h_counts[1])) return rce;
     if (off[nblocks] > c->out_cap) return fail(M4G_ERR_HIP, "internal: match count above bound");
     std::vector<uint64_t> lens(nblocks);
-    for (size_t b = 0; b < nblocks; b++) lens[b] = std::min<uint64_t>(block_size, n - b * block_size);
+    for (size_t b = 0; b < nblocks; b++) lens[b] = std::min<uint64_t>(block_size, n - skip - b * block_size);
     if ((rc = hook->fn(c->d_hist, d_blocks, lens, c->d_out, c->d_boff, off[nblocks], c->st))) return rc;
     tr.mark("blocks: encoder hook");
   }
 
   // the handle continues as after the last block's call: history = buffer from the final origin on
-  const uint64_t new_len = x_end - org;
-  if (org > 0) {
+  // (span mode: the handle stays fresh)
+  const uint64_t new_len = sm ? 0 : x_end - org;
+  if (org > 0 && !sm) {
     if (org >= new_len) {
       HIP_TRY(hipMemcpyAsync(c->d_hist, c->d_hist + org, new_len, hipMemcpyDeviceToDevice, c->st));
       HIP_TRY(hipMemcpyAsync(c->d_chain, c->d_chain + org, new_len * 4, hipMemcpyDeviceToDevice, c->st));
@@ -2694,6 +2715,168 @@ int64_t find_blocks_impl(m4g_ctx *c, const uint8_t *src, size_t n, size_t block_
   return (int64_t)cnt;
 }
 } // namespace
+
+// ===========================================================================
+// One stream over several devices (protocol P1): include/m4g.h,
+// m4g_find_matches_blocks_multi.
+// ===========================================================================
+namespace {
+// One piece of the plan: blocks [b0, b1) of the stream go to devices[dev]; the device gets the bytes from `lo`
+// (a block boundary at or below the origin in force for block b0) to the end of block b1 - 1.
+struct SpanPiece {
+  uint32_t dev;
+  uint64_t b0, b1, lo;
+};
+// m4.go:82-99 replayed over the block lengths of the whole stream: the buffer origin (absolute stream offset of
+// history[0]) in force while block b is parsed.
+void stream_origins(uint64_t n, uint64_t bs, uint64_t W, std::vector<uint64_t> &org) {
+  const uint64_t nblocks = (n + bs - 1) / bs;
+  org.resize(nblocks);
+  uint64_t origin = 0, hlen = 0;
+  for (uint64_t b = 0; b < nblocks; b++) {
+    if (hlen > 2 * W) { // the slide happens BEFORE the append
+      origin += hlen - W;
+      hlen = W;
+    }
+    org[b] = origin;
+    hlen += std::min(bs, n - b * bs);
+  }
+}
+// Contiguous ranges of whole blocks, one per device, each cut into pieces that one launch can hold: at most
+// kStreamMaxSlides - 3 origin changes, fewer than 2^24 blocks, and (history + piece) below max_piece_bytes.
+void plan_spans(uint64_t n, uint64_t bs, uint64_t W, int ndev, uint64_t max_piece_bytes, const std::vector<uint64_t> &org,
+                std::vector<SpanPiece> &plan) {
+  const uint64_t nblocks = org.size();
+  const uint64_t per = (nblocks + (uint64_t)ndev - 1) / (uint64_t)ndev;
+  for (int d = 0; d < ndev; d++) {
+    const uint64_t d0 = std::min(nblocks, (uint64_t)d * per), d1 = std::min(nblocks, d0 + per);
+    uint64_t b0 = d0;
+    while (b0 < d1) {
+      const uint64_t lo = org[b0] / bs * bs;
+      uint64_t b1 = b0 + 1, moves = 0;
+      while (b1 < d1) {
+        const uint64_t m = moves + (org[b1] != org[b1 - 1] ? 1 : 0);
+        const uint64_t end = std::min(n, (b1 + 1) * bs);
+        if (m + 3 >= (uint64_t)kStreamMaxSlides || b1 + 1 - b0 >= ((uint64_t)1 << 24) || end - lo > max_piece_bytes) break;
+        moves = m;
+        b1++;
+      }
+      plan.push_back(SpanPiece{(uint32_t)d, b0, b1, lo});
+      b0 = b1;
+    }
+  }
+}
+constexpr uint64_t kSpanPieceBytes = (uint64_t)768 << 20; // bytes a device holds per launch (history included)
+} // namespace
+
+extern "C" int64_t m4g_debug_span_plan(const m4g_params *params, size_t n, size_t block_size, int ndevices,
+                                       uint64_t *pieces /* 4 per piece: dev, b0, b1, lo */, size_t cap,
+                                       uint64_t *origins /* nullable, one per block */) {
+  Params p;
+  if (int rc = resolve_params(params, &p)) return rc;
+  if (block_size == 0 || ndevices <= 0) return fail(M4G_ERR_BAD_PARAM, "block_size 0 or no device");
+  std::vector<uint64_t> org;
+  stream_origins(n, block_size, (uint64_t)p.max_distance, org);
+  std::vector<SpanPiece> plan;
+  plan_spans(n, block_size, (uint64_t)p.max_distance, ndevices, kSpanPieceBytes, org, plan);
+  if (origins) std::copy(org.begin(), org.end(), origins);
+  for (size_t k = 0; k < plan.size() && k < cap; k++) {
+    pieces[4 * k] = plan[k].dev, pieces[4 * k + 1] = plan[k].b0, pieces[4 * k + 2] = plan[k].b1, pieces[4 * k + 3] = plan[k].lo;
+  }
+  return (int64_t)plan.size();
+}
+
+extern "C" int64_t m4g_find_matches_blocks_multi(const m4g_params *params, const int *devices, int ndevices,
+                                                 const uint8_t *src, size_t n, size_t block_size, m4g_match *out,
+                                                 size_t out_cap, uint64_t *block_off) {
+  Params p;
+  if (int rc = resolve_params(params, &p)) return rc;
+  if (!devices || ndevices <= 0 || (!src && n) || (!out && out_cap) || block_size == 0)
+    return fail(M4G_ERR_BAD_PARAM, "NULL argument, no device or block_size 0");
+  if (n >= ((uint64_t)1 << 40)) return fail(M4G_ERR_TOO_LARGE, "at most 1 TiB per stream");
+  for (int d = 0; d < ndevices; d++)
+    if (int rc = check_device(devices[d])) return rc;
+  const size_t nblocks = (n + block_size - 1) / block_size;
+  size_t need = 0;
+  for (size_t b = 0; b < nblocks; b++) need += std::min(block_size, n - b * block_size) / (size_t)p.min_length + 2;
+  if (out_cap < need && n != 0) {
+    g_last_error = "out_cap below the sum of len/min_length + 2 over the blocks";
+    return -(int64_t)(need + M4G_STREAM_NEEDED_BIAS);
+  }
+  if (block_off) block_off[0] = 0;
+  if (n == 0) return 0;
+  const uint64_t W = (uint64_t)p.max_distance;
+  const bool shape_ok = block_size >= (size_t)kK1MaxTile + 7 && W >= (uint64_t)kK1MaxTile;
+  if (!shape_ok || nblocks < 2) {
+    // tiny blocks or a tiny window: the block-by-block path of one handle (nothing to spread)
+    if (n >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "this block shape runs on one handle: below 2^31 bytes");
+    m4g_ctx *c = nullptr;
+    if (int rc = m4g_create(params, devices[0], &c)) return rc;
+    const int64_t r = find_blocks_impl(c, src, n, block_size, out, out_cap, block_off, nullptr);
+    m4g_destroy(c);
+    return r;
+  }
+  std::vector<uint64_t> org;
+  stream_origins(n, block_size, W, org);
+  std::vector<SpanPiece> plan;
+  plan_spans(n, block_size, W, ndevices, kSpanPieceBytes, org, plan);
+
+  // one host thread per device; every piece into its own list, joined in stream order afterwards
+  struct PieceOut {
+    std::vector<m4g_match> m;
+    std::vector<uint64_t> off;
+    int64_t count = 0;
+  };
+  std::vector<PieceOut> res(plan.size());
+  std::vector<int64_t> rcs((size_t)ndevices, 0);
+  std::vector<std::string> errs((size_t)ndevices);
+  auto work = [&](int d) {
+    m4g_ctx *c = nullptr;
+    int64_t rc = m4g_create(params, devices[d], &c);
+    for (size_t k = 0; k < plan.size() && rc == 0; k++) {
+      const SpanPiece &S = plan[k];
+      if ((int)S.dev != d) continue;
+      const uint64_t x0 = S.b0 * block_size, x1 = std::min<uint64_t>(n, S.b1 * block_size);
+      const size_t nb = (size_t)(S.b1 - S.b0);
+      std::vector<uint64_t> o(nb);
+      for (size_t b = 0; b < nb; b++) o[b] = org[S.b0 + b] - S.lo;
+      size_t cap = 0;
+      for (size_t b = 0; b < nb; b++) cap += (size_t)(std::min<uint64_t>(n, (S.b0 + b + 1) * block_size) - (S.b0 + b) * block_size) / (size_t)p.min_length + 2;
+      res[k].m.resize(cap);
+      res[k].off.resize(nb + 1);
+      SpanMode sm{(size_t)(x0 - S.lo), o.data()};
+      const int64_t r = find_blocks_impl(c, src + S.lo, (size_t)(x1 - S.lo), block_size, res[k].m.data(), cap, res[k].off.data(),
+                                         nullptr, &sm);
+      if (r < 0) rc = r;
+      else res[k].count = r;
+    }
+    if (rc) errs[(size_t)d] = g_last_error; // (thread-local: carried to the caller's thread below)
+    if (c) m4g_destroy(c);
+    rcs[(size_t)d] = rc;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int d = 1; d < ndevices; d++) th.emplace_back(work, d);
+    work(0);
+    for (auto &t : th) t.join();
+  }
+  for (int d = 0; d < ndevices; d++)
+    if (rcs[(size_t)d]) {
+      if (d) g_last_error = errs[(size_t)d];
+      return rcs[(size_t)d];
+    }
+  // ordered concatenation (pieces are in stream order: devices take ascending ranges)
+  uint64_t total = 0;
+  for (size_t k = 0; k < plan.size(); k++) {
+    const size_t nb = (size_t)(plan[k].b1 - plan[k].b0);
+    if (total + (uint64_t)res[k].count > out_cap) return fail(M4G_ERR_INTERNAL, "match count above bound");
+    if (res[k].count) std::memcpy(out + total, res[k].m.data(), (size_t)res[k].count * sizeof(m4g_match));
+    if (block_off)
+      for (size_t b = 1; b <= nb; b++) block_off[plan[k].b0 + b] = total + res[k].off[b];
+    total += (uint64_t)res[k].count;
+  }
+  return (int64_t)total;
+}
 
 extern "C" int m4g_debug_dump_tables(m4g_ctx *c, uint32_t *table, uint32_t *chain, size_t chain_cap) {
   if (!c) return fail(M4G_ERR_BAD_PARAM, "ctx is NULL");

@@ -44,7 +44,7 @@ EXPORTS = [
     "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_batch_run_device_codes",
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
-    "m4g_batch_status", "m4g_batch_run_device_noalloc", "m4g_debug_noalloc_poison",
+    "m4g_batch_status", "m4g_batch_run_device_noalloc", "m4g_debug_noalloc_poison", "m4g_find_matches_blocks_multi", "m4g_debug_span_plan",
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
     "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
     "m4g_bargain_create", "m4g_bargain_destroy", "m4g_bargain_block_count", "m4g_bargain_run_device",
@@ -135,6 +135,10 @@ def lib():
         L.m4g_writer_destroy.restype = None
         L.m4g_batch_run_device_noalloc.argtypes = [ctypes.POINTER(Params), ctypes.c_int, vp, vp, sz, vp, vp, sz, vp, vp]
         L.m4g_debug_noalloc_poison.argtypes = [ctypes.c_int, ctypes.c_int, vp]
+        L.m4g_find_matches_blocks_multi.argtypes = [ctypes.POINTER(Params), vp, ctypes.c_int, vp, sz, sz, vp, sz, vp]
+        L.m4g_find_matches_blocks_multi.restype = ctypes.c_int64
+        L.m4g_debug_span_plan.argtypes = [ctypes.POINTER(Params), sz, sz, ctypes.c_int, vp, sz, vp]
+        L.m4g_debug_span_plan.restype = ctypes.c_int64
         L.m4g_bargain_create.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, sz, sz, sz, ctypes.POINTER(vp)]
         L.m4g_bargain_destroy.argtypes = [vp]
         L.m4g_bargain_destroy.restype = None
@@ -596,14 +600,18 @@ class NewWriterV2(GPUWriter):
         self._buf = np.zeros(1 << 20, dtype=np.uint8)
 
 
-def brotli_compress(data, block_size: int = 1 << 16, device: int = 0, **m4_fields) -> bytes:
+def brotli_compress(data, block_size: int = 1 << 16, device: int = 0, devices: "Sequence[int] | None" = None,
+                    **m4_fields) -> bytes:
     """matchfinder.Writer{MatchFinder: &matchfinder.M4{**m4_fields}, Encoder: &brotli.Encoder{}, BlockSize}:
     w.Write(data); w.Close() -- the writer of the reference's tests (brotli_test.go:626-649, 730-744) -- with
     match finding (m4g_find_matches_blocks) and both passes of Encoder.Encode (m4g_brotli_encode_blocks) on the
     GPU.  Returns the brotli stream."""
     a = _as_u8(data)
-    mf = M4(device=device, **m4_fields)
-    matches, off = mf.find_matches_blocks(a, block_size)
+    if devices:  # the stream's blocks over several devices (m4g_find_matches_blocks_multi), the encoder on the first
+        device = devices[0]
+        matches, off = find_matches_blocks_multi(a, block_size, devices, **m4_fields)
+    else:
+        matches, off = M4(device=device, **m4_fields).find_matches_blocks(a, block_size)
     cap = a.size + (a.size // block_size + 2) * 1024 + 64
     buf = np.zeros(cap, dtype=np.uint8)
     m = np.ascontiguousarray(matches, dtype=np.uint32)
@@ -640,15 +648,18 @@ def brotli_compress_v2(data, level: int = 5, device: int = 0) -> bytes:
 
 
 def flate_compress(data, level: int = 6, gzip: bool = False, mtime: int = 0, block_size: int = 1 << 16,
-                   device: int = 0) -> bytes:
+                   device: int = 0, devices: "Sequence[int] | None" = None) -> bytes:
     """flate.NewWriter(dst, level) / flate.NewGZIPWriter(dst, level) for the levels whose match finder is
     matchfinder.M4 (5..7; flate/writer.go:23-66): w.Write(data); w.Close().  Match finding for all blocks in
     one launch (m4g_find_matches_blocks: the Match lists of the writer's block-after-block FindMatches calls,
     history carried over), then the encoder on the GPU (m4g_flate_encode_blocks).  `mtime` stands in for the
     time.Now() of the gzip header (flate/gzip.go:46)."""
     a = _as_u8(data)
-    mf = M4(device=device, **flate_m4_params(level))
-    matches, off = mf.find_matches_blocks(a, block_size)
+    if devices:  # (as brotli_compress)
+        device = devices[0]
+        matches, off = find_matches_blocks_multi(a, block_size, devices, **flate_m4_params(level))
+    else:
+        matches, off = M4(device=device, **flate_m4_params(level)).find_matches_blocks(a, block_size)
     cap = a.size + (a.size // block_size + 2) * 16 + 64
     buf = np.zeros(cap, dtype=np.uint8)
     m = np.ascontiguousarray(matches, dtype=np.uint32)
@@ -666,6 +677,39 @@ def flate_m4_params(level: int) -> dict:
     if not 5 <= level <= 7:
         raise ValueError("flate levels 5..7 are the ones that use matchfinder.M4")
     return dict(MaxDistance=1 << 15, ChainLength={5: 8, 6: 16, 7: 32}[level], HashLen=5, DistanceBitCost=66)
+
+
+def find_matches_blocks_multi(src, block_size: int, devices: Sequence[int] = (0,), **m4_fields):
+    """m4g_find_matches_blocks_multi: a fresh M4's FindMatches over every consecutive block of src, the blocks
+    spread over `devices` (one stream over several GPUs); returns (matches[M,3], block_off[nblocks+1])."""
+    a = _as_u8(src)
+    p = _params(m4_fields.get("MaxDistance", 0), m4_fields.get("MinLength", 0), m4_fields.get("HashLen", 0),
+                m4_fields.get("TableBits", 0), m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
+    min_len = p.min_length or 4
+    nblocks = (a.size + block_size - 1) // block_size
+    cap = sum(min(block_size, a.size - b * block_size) // min_len + 2 for b in range(nblocks)) + 1
+    out = np.empty((cap, 3), dtype=np.uint32)
+    off = np.zeros(nblocks + 1, dtype=np.uint64)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    r = lib().m4g_find_matches_blocks_multi(ctypes.byref(p), devs, len(devices), a.ctypes.data if a.size else None,
+                                            a.size, block_size, out.ctypes.data, cap, off.ctypes.data)
+    _check(r, "m4g_find_matches_blocks_multi")
+    if r < 0:
+        raise M4GError(f"m4g_find_matches_blocks_multi: out_cap too small, need {-r - STREAM_NEEDED_BIAS}")
+    return out[:r], off
+
+
+def span_plan(n: int, block_size: int, ndevices: int, **m4_fields):
+    """m4g_debug_span_plan: (pieces[k, 4] = device slot, first block, end block, first byte; origins[nblocks])."""
+    p = _params(m4_fields.get("MaxDistance", 0), m4_fields.get("MinLength", 0), m4_fields.get("HashLen", 0),
+                m4_fields.get("TableBits", 0), m4_fields.get("ChainLength", 0), m4_fields.get("DistanceBitCost", 0))
+    nblocks = (n + block_size - 1) // block_size
+    org = np.zeros(max(nblocks, 1), dtype=np.uint64)
+    k = lib().m4g_debug_span_plan(ctypes.byref(p), n, block_size, ndevices, None, 0, org.ctypes.data)
+    _check(k, "m4g_debug_span_plan")
+    pieces = np.zeros((max(k, 1), 4), dtype=np.uint64)
+    lib().m4g_debug_span_plan(ctypes.byref(p), n, block_size, ndevices, pieces.ctypes.data, k, None)
+    return pieces[:k], org[:nblocks]
 
 
 def noalloc_poison(value: int = 0xFF, device: int = 0, stream: int = 0):

@@ -150,6 +150,30 @@ int64_t m4g_find_matches_blocks(m4g_ctx *ctx, const uint8_t *src, size_t n,
                                 size_t block_size, m4g_match *out,
                                 size_t out_cap, uint64_t *block_off);
 
+/* ONE stream over several devices (protocol P1).  Replaces:
+ *   m := &matchfinder.M4{params}
+ *   for each block of block_size bytes of src: m.FindMatches(nil, block)
+ * i.e. what matchfinder.Writer (matchfinder.go:59-93) asks of a fresh M4 over a
+ * whole input -- with the blocks spread over `devices`: device d parses a
+ * contiguous range of whole blocks and is handed, besides them, the bytes from
+ * the buffer origin in force for its first block (m4.go:82-99 replayed on the
+ * host over the whole stream), which lies at least MaxDistance below it once
+ * the stream has slid.  No device talks to another; one host thread per
+ * device; the per-block Match lists are joined in stream order on the host.
+ * Arguments and results as m4g_find_matches_blocks on a fresh handle; returns
+ * the number of Matches, -(needed + M4G_STREAM_NEEDED_BIAS) when out_cap is too
+ * small, or an M4G_ERR_*.  A device index may be listed more than once (its
+ * ranges then run side by side on that device). */
+int64_t m4g_find_matches_blocks_multi(const m4g_params *params, const int *devices, int ndevices,
+                                      const uint8_t *src, size_t n, size_t block_size, m4g_match *out,
+                                      size_t out_cap, uint64_t *block_off);
+/* Debug / tests: the plan of the call above -- per piece {device slot, first
+ * block, end block, first byte handed over}, and per block the buffer origin
+ * (absolute stream offset) in force while it is parsed.  Returns the number
+ * of pieces (fills at most cap of them).  No device is touched. */
+int64_t m4g_debug_span_plan(const m4g_params *params, size_t n, size_t block_size, int ndevices,
+                            uint64_t *pieces, size_t cap, uint64_t *origins);
+
 /* Debug / parity: copy the handle's hash table (1<<table_bits entries) and
  * chain deltas (one per history byte; reference keeps them only when
  * ChainLength > 0, this implementation always) to host memory.  Either
