@@ -362,6 +362,188 @@ extern "C" int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int
   return r;
 }
 
+namespace {
+template <class T> int grow_dev(T **p, size_t *cap, size_t need) {
+  if (need <= *cap) return M4G_OK;
+  (void)hipFree(*p);
+  *p = nullptr, *cap = 0;
+  const size_t want = need + need / 2 + 64;
+  if (hipMalloc(reinterpret_cast<void **>(p), want * sizeof(T)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(M4G_ERR_NO_MEMORY, "device allocation failed (Bargain handle)");
+  }
+  *cap = want;
+  return M4G_OK;
+}
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Bargain1 / Bargain2 / Bargain3 as a matchfinder.MatchFinder: a handle with FindMatches / Reset
+// (bargain1.go:33-38, 66-84; writer.go:142-150 plugs it into matchfinder.Writer).  include/m4g.h.
+// ---------------------------------------------------------------------------
+struct m4g_bargain_ctx {
+  m4g_bargain_params bp{};
+  BargainDesc d;
+  int device = 0;
+  std::vector<uint8_t> hist;  // the stream's last whole blocks, MaxDistance bytes or more (host copy)
+  std::vector<uint8_t> chunk; // [hist | new blocks], staged for the upload
+  bool tail_seen = false;     // a block shorter than block_size was found: the stream's last one
+  m4g_bargain *plan = nullptr;
+  size_t plan_bytes = 0;
+  uint8_t *d_src = nullptr;
+  m4g_match *d_m = nullptr;
+  uint64_t *d_off = nullptr;
+  size_t d_src_cap = 0, d_m_cap = 0, d_off_cap = 0;
+};
+
+extern "C" void m4g_bargain_ctx_destroy(m4g_bargain_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  m4g_bargain_destroy(c->plan);
+  (void)hipFree(c->d_src);
+  (void)hipFree(c->d_m);
+  (void)hipFree(c->d_off);
+  delete c;
+}
+
+extern "C" int m4g_bargain_ctx_create(const m4g_bargain_params *params, int device, m4g_bargain_ctx **out) {
+  if (!out) return fail(M4G_ERR_BAD_PARAM, "out is NULL");
+  *out = nullptr;
+  BargainDesc d;
+  if (int rc = bargain_desc(params, &d)) return rc;
+  if (int rc = check_device(device)) return rc;
+  if (d.P.skip && ((d.P.block_size | d.P.max_distance) & 1))
+    // bargain1.go:159 tests the parity of the HISTORY position; the handle cuts the history at block boundaries
+    return fail(M4G_ERR_BAD_PARAM, "Skip needs an even block_size and MaxDistance on this handle");
+  m4g_bargain_ctx *c = new (std::nothrow) m4g_bargain_ctx();
+  if (!c) return fail(M4G_ERR_NO_MEMORY, "host allocation failed");
+  c->bp = *params;
+  c->d = d;
+  c->device = device;
+  *out = c;
+  return M4G_OK;
+}
+
+// bargain1.go:33-36
+extern "C" int m4g_bargain_ctx_reset(m4g_bargain_ctx *c) {
+  if (!c) return fail(M4G_ERR_BAD_PARAM, "ctx is NULL");
+  c->hist.clear();
+  c->tail_seen = false;
+  return M4G_OK;
+}
+
+// FindMatches on every consecutive block of block_size bytes of src, continuing the handle's stream
+// (n = one block: FindMatches itself).  block_off: nullable.
+extern "C" int64_t m4g_bargain_ctx_find_blocks(m4g_bargain_ctx *c, const uint8_t *src, size_t n, m4g_match *out,
+                                               size_t out_cap, uint64_t *block_off) {
+  if (!c || (!src && n) || (!out && out_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
+  if (block_off) block_off[0] = 0;
+  if (n == 0) return 0; // bargain1.go:38-64 on an empty block: nothing inserted, nothing emitted
+  const size_t bs = c->d.P.block_size;
+  if (c->tail_seen)
+    return fail(M4G_ERR_BAD_PARAM, "m4g_bargain_ctx: a block shorter than block_size ends the stream (matchfinder.Writer's "
+                                   "shape); m4g_bargain_ctx_reset starts the next one");
+  const size_t hist = c->hist.size(), total = hist + n, nb = (n + bs - 1) / bs;
+  if (total >= ((uint64_t)1 << 31)) return fail(M4G_ERR_TOO_LARGE, "at most 2 GiB of history + data per call");
+  const size_t need = n / 3 + 2 * nb + 8; // a Match is at least 3 bytes long, plus one literal-only record per block
+  if (out_cap < need) {
+    g_last_error = "out_cap below n / 3 + 2 * blocks + 8";
+    return -(int64_t)(need + M4G_STREAM_NEEDED_BIAS);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  c->chunk.resize(total);
+  if (hist) std::memcpy(c->chunk.data(), c->hist.data(), hist);
+  std::memcpy(c->chunk.data() + hist, src, n);
+  if (int rc = grow_dev(&c->d_src, &c->d_src_cap, total + 64)) return rc;
+  if (int rc = grow_dev(&c->d_m, &c->d_m_cap, need)) return rc;
+  if (int rc = grow_dev(&c->d_off, &c->d_off_cap, nb + 2)) return rc;
+  if (!c->plan || total > c->plan_bytes) {
+    m4g_bargain_destroy(c->plan);
+    c->plan = nullptr;
+    const size_t cap = std::max<size_t>(total + total / 2, (size_t)4 << 20);
+    if (int rc = m4g_bargain_create(&c->bp, c->device, 1, cap, cap, &c->plan)) return rc;
+    c->plan_bytes = cap;
+  }
+  HIP_TRY(hipMemcpy(c->d_src, c->chunk.data(), total, hipMemcpyHostToDevice));
+  const uint64_t chunk_off[2] = {0, total};
+  const int64_t r = bargain_run_impl(c->plan, c->d_src, chunk_off, 1, c->d_m, c->d_m_cap, c->d_off, nullptr, (uint32_t)hist);
+  if (r < 0) return r < -(int64_t)M4G_STREAM_NEEDED_BIAS ? fail(M4G_ERR_INTERNAL, "Match list larger than its bound") : r;
+  if (r) HIP_TRY(hipMemcpy(out, c->d_m, (size_t)r * sizeof(m4g_match), hipMemcpyDeviceToHost));
+  if (block_off) HIP_TRY(hipMemcpy(block_off, c->d_off, (nb + 1) * 8, hipMemcpyDeviceToHost));
+  // what the next call needs of the stream: its last whole blocks, MaxDistance bytes or more
+  if (n % bs) {
+    c->tail_seen = true;
+  } else {
+    const size_t keep = ((size_t)c->d.P.max_distance + bs - 1) / bs * bs;
+    if (total > keep) c->hist.assign(c->chunk.begin() + (ptrdiff_t)(total - keep), c->chunk.end());
+    else c->hist = c->chunk;
+  }
+  return r;
+}
+
+// One stream over several devices: the Match lists of m4g_bargain_find_blocks, every device with a contiguous range
+// of blocks and the whole blocks (MaxDistance bytes or more) before it as history -- the same cut the handle above
+// makes between calls.
+extern "C" int64_t m4g_bargain_find_blocks_multi(const m4g_bargain_params *params, const int *devices, int ndevices,
+                                                 const uint8_t *src, size_t n, m4g_match *out, size_t out_cap,
+                                                 uint64_t *block_off) {
+  if (!devices || ndevices <= 0 || (!src && n) || (!out && out_cap) || !block_off)
+    return fail(M4G_ERR_BAD_PARAM, "NULL argument or no device");
+  BargainDesc d;
+  if (int rc = bargain_desc(params, &d)) return rc;
+  block_off[0] = 0;
+  if (n == 0) return 0;
+  const size_t bs = d.P.block_size, nblocks = (n + bs - 1) / bs;
+  const size_t keep = ((size_t)d.P.max_distance + bs - 1) / bs * bs;
+  const size_t per = (nblocks + (size_t)ndevices - 1) / (size_t)ndevices;
+  struct Part {
+    std::vector<m4g_match> m;
+    std::vector<uint64_t> off;
+    int64_t r = 0;
+    std::string err;
+  };
+  std::vector<Part> parts((size_t)ndevices);
+  auto work = [&](int dv) {
+    Part &P = parts[(size_t)dv];
+    const size_t b0 = std::min(nblocks, (size_t)dv * per), b1 = std::min(nblocks, b0 + per);
+    if (b0 >= b1) return;
+    const size_t x0 = b0 * bs, x1 = std::min(n, b1 * bs), lo = x0 > keep ? x0 - keep : 0;
+    m4g_bargain_ctx *c = nullptr;
+    int64_t rc = m4g_bargain_ctx_create(params, devices[dv], &c);
+    if (rc == 0) {
+      c->hist.assign(src + lo, src + x0); // (whole blocks: lo and x0 are block boundaries)
+      const size_t nb = b1 - b0, len = x1 - x0;
+      P.m.resize(len / 3 + 2 * nb + 8);
+      P.off.resize(nb + 1);
+      rc = m4g_bargain_ctx_find_blocks(c, src + x0, len, P.m.data(), P.m.size(), P.off.data());
+    }
+    if (rc < 0) P.err = g_last_error;
+    P.r = rc;
+    m4g_bargain_ctx_destroy(c);
+  };
+  {
+    std::vector<std::thread> th;
+    for (int dv = 1; dv < ndevices; dv++) th.emplace_back(work, dv);
+    work(0);
+    for (auto &t : th) t.join();
+  }
+  uint64_t total = 0;
+  for (int dv = 0; dv < ndevices; dv++) {
+    Part &P = parts[(size_t)dv];
+    if (P.r < 0) {
+      g_last_error = P.err;
+      return P.r;
+    }
+    const size_t b0 = std::min(nblocks, (size_t)dv * per), b1 = std::min(nblocks, b0 + per);
+    if (b0 >= b1) continue;
+    if (total + (uint64_t)P.r > out_cap) return -(int64_t)(n / 3 + 2 * nblocks + 8 + M4G_STREAM_NEEDED_BIAS);
+    if (P.r) std::memcpy(out + total, P.m.data(), (size_t)P.r * sizeof(m4g_match));
+    for (size_t b = 1; b <= b1 - b0; b++) block_off[b0 + b] = total + P.off[b];
+    total += (uint64_t)P.r;
+  }
+  return (int64_t)total;
+}
+
 // w := brotli.NewWriterV2(dst, level); w.Write(src); w.Close() for the levels whose MatchFinder is one of the
 // Bargain finders (writer.go:126-161): level 5, 6 Bargain1, 7 Bargain2 with Skip, 8 Bargain2, 9 (and above) Bargain3,
 // MaxDistance 1 << 20, BlockSize 1 << 16, Encoder &brotli.Encoder{}.  Host memory in, the brotli stream out.
@@ -425,18 +607,6 @@ extern "C" int64_t m4g_brotli_compress_v2(int level, int device, const uint8_t *
 
 // ---- matchfinder.Writer with a Bargain finder: brotli.NewWriterV2(dst, 5..9) as a streaming handle -------------
 namespace {
-template <class T> int grow_dev(T **p, size_t *cap, size_t need) {
-  if (need <= *cap) return M4G_OK;
-  (void)hipFree(*p);
-  *p = nullptr, *cap = 0;
-  const size_t want = need + need / 2 + 64;
-  if (hipMalloc(reinterpret_cast<void **>(p), want * sizeof(T)) != hipSuccess) {
-    (void)hipGetLastError();
-    return fail(M4G_ERR_NO_MEMORY, "device allocation failed (m4g_writer, Bargain)");
-  }
-  *cap = want;
-  return M4G_OK;
-}
 
 // The blocks of `span` (whole blocks of bs bytes; final: Close()'s remainder, shorter than a block, possibly empty).
 // The finder sees the stream so far through the bytes kept in w->bhist: whole blocks, at least MaxDistance of them once

@@ -44,7 +44,7 @@ EXPORTS = [
     "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_batch_run_device_codes",
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
-    "m4g_batch_status", "m4g_batch_run_device_noalloc", "m4g_debug_noalloc_poison", "m4g_find_matches_blocks_multi", "m4g_debug_span_plan",
+    "m4g_batch_status", "m4g_batch_run_device_noalloc", "m4g_debug_noalloc_poison", "m4g_find_matches_blocks_multi", "m4g_debug_span_plan", "m4g_bargain_ctx_create", "m4g_bargain_ctx_destroy", "m4g_bargain_ctx_reset", "m4g_bargain_ctx_find_blocks", "m4g_bargain_find_blocks_multi",
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
     "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
     "m4g_bargain_create", "m4g_bargain_destroy", "m4g_bargain_block_count", "m4g_bargain_run_device",
@@ -149,6 +149,14 @@ def lib():
         L.m4g_bargain_last_timings.argtypes = [vp, vp, ctypes.c_int]
         L.m4g_bargain_find_blocks.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, vp, sz, vp, sz, vp]
         L.m4g_bargain_find_blocks.restype = ctypes.c_int64
+        L.m4g_bargain_ctx_create.argtypes = [ctypes.POINTER(BargainParams), ctypes.c_int, ctypes.POINTER(vp)]
+        L.m4g_bargain_ctx_destroy.argtypes = [vp]
+        L.m4g_bargain_ctx_destroy.restype = None
+        L.m4g_bargain_ctx_reset.argtypes = [vp]
+        L.m4g_bargain_ctx_find_blocks.argtypes = [vp, vp, sz, vp, sz, vp]
+        L.m4g_bargain_ctx_find_blocks.restype = ctypes.c_int64
+        L.m4g_bargain_find_blocks_multi.argtypes = [ctypes.POINTER(BargainParams), vp, ctypes.c_int, vp, sz, vp, sz, vp]
+        L.m4g_bargain_find_blocks_multi.restype = ctypes.c_int64
         L.m4g_writer_create_v2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
         L.m4g_brotli_compress_v2.argtypes = [ctypes.c_int, ctypes.c_int, vp, sz, vp, sz]
         L.m4g_brotli_compress_v2.restype = ctypes.c_int64
@@ -518,6 +526,71 @@ class BargainPlan:
         return [float(ms[k]) for k in range(n)]
 
 
+class Bargain:
+    """``matchfinder.Bargain1`` / ``Bargain2`` / ``Bargain3`` (variant 1 / 2 / 3; bargain1.go:15-31) as a
+    ``matchfinder.MatchFinder`` on an MI355X: ``FindMatches(dst, src)`` / ``Reset()`` (m4g_bargain_ctx_*).  The blocks
+    of a stream must be ``BlockSize`` bytes each, a shorter one only as the last before ``Reset`` -- the shape
+    ``matchfinder.Writer{BlockSize}`` produces; ``find_matches_blocks`` is the same for many blocks in one launch."""
+
+    def __init__(self, variant: int = 1, MaxDistance: int = 0, Skip: bool = False, BlockSize: int = 1 << 16,
+                 device: int = 0):
+        self.variant, self.MaxDistance, self.Skip, self.BlockSize, self.device = variant, MaxDistance, Skip, BlockSize, device
+        h = ctypes.c_void_p()
+        P = BargainParams(variant, MaxDistance, 1 if Skip else 0, BlockSize)
+        _check(lib().m4g_bargain_ctx_create(ctypes.byref(P), device, ctypes.byref(h)), "m4g_bargain_ctx_create")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().m4g_bargain_ctx_destroy(self._h)
+            self._h = None
+
+    def Reset(self):
+        _check(lib().m4g_bargain_ctx_reset(self._h), "m4g_bargain_ctx_reset")
+
+    def find_matches_blocks(self, src, block_size: "int | None" = None):
+        """FindMatches on every consecutive block of src, continuing the stream: (matches[M,3], block_off)."""
+        a = _as_u8(src)
+        bs = self.BlockSize or (1 << 16)
+        if block_size not in (None, bs):
+            raise M4GError("Bargain: the block size is fixed when the finder is made (BlockSize)")
+        nb = (a.size + bs - 1) // bs
+        cap = a.size // 3 + 2 * nb + 8
+        out = np.empty((cap, 3), dtype=np.uint32)
+        off = np.zeros(nb + 1, dtype=np.uint64)
+        r = lib().m4g_bargain_ctx_find_blocks(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap,
+                                              off.ctypes.data)
+        _check(r, "m4g_bargain_ctx_find_blocks")
+        if r < 0:
+            raise M4GError(f"m4g_bargain_ctx_find_blocks: out_cap too small, need {-r - STREAM_NEEDED_BIAS}")
+        return out[:r], off
+
+    def FindMatches(self, dst: List[Match], src) -> List[Match]:
+        """matchfinder.MatchFinder.FindMatches: append to dst, return dst (one block)."""
+        m, _ = self.find_matches_blocks(src)
+        dst.extend((int(u), int(l), int(d)) for u, l, d in m.tolist())
+        return dst
+
+
+def bargain_find_blocks_multi(data, devices: Sequence[int], variant: int = 1, MaxDistance: int = 1 << 20,
+                              Skip: bool = False, BlockSize: int = 1 << 16):
+    """m4g_bargain_find_blocks_multi: bargain_find_blocks with the blocks spread over `devices`."""
+    a = _as_u8(data)
+    P = BargainParams(variant, MaxDistance, 1 if Skip else 0, BlockSize)
+    bs = BlockSize or (1 << 16)
+    nb = (a.size + bs - 1) // bs
+    cap = a.size // 3 + 2 * nb + 8
+    out = np.empty((cap, 3), dtype=np.uint32)
+    off = np.zeros(nb + 1, dtype=np.uint64)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    r = lib().m4g_bargain_find_blocks_multi(ctypes.byref(P), devs, len(devices), a.ctypes.data if a.size else None, a.size,
+                                            out.ctypes.data, cap, off.ctypes.data)
+    _check(r, "m4g_bargain_find_blocks_multi")
+    if r < 0:
+        raise M4GError(f"m4g_bargain_find_blocks_multi: out_cap too small, need {-r - STREAM_NEEDED_BIAS}")
+    return out[:r], off
+
+
 def bargain_find_blocks(data, variant: int = 1, MaxDistance: int = 1 << 20, Skip: bool = False,
                         BlockSize: int = 1 << 16, device: int = 0):
     """The FindMatches calls of matchfinder.Writer{MatchFinder: &Bargain1{...} | &Bargain2{...}, BlockSize}
@@ -633,13 +706,20 @@ def writer_v2_match_finder(level: int) -> dict:
     return {"variant": v, "MaxDistance": 1 << 20, "Skip": skip, "BlockSize": 1 << 16}
 
 
-def brotli_compress_v2(data, level: int = 5, device: int = 0) -> bytes:
+def brotli_compress_v2(data, level: int = 5, device: int = 0, devices: "Sequence[int] | None" = None) -> bytes:
     """w := brotli.NewWriterV2(dst, level); w.Write(data); w.Close() for level 5-9 (writer.go:126-161):
     matchfinder.Writer{Bargain1 | Bargain2 | Bargain3, &Encoder{}, BlockSize 1 << 16} with the match finder and both
     passes of Encoder.Encode on the GPU (m4g_brotli_compress_v2)."""
     a = _as_u8(data)
     cap = a.size + (a.size // (1 << 16) + 2) * 1024 + 64
     buf = np.zeros(cap, dtype=np.uint8)
+    if devices:  # the stream's blocks over several devices (m4g_bargain_find_blocks_multi), the encoder on the first
+        m, off = bargain_find_blocks_multi(a, devices, **writer_v2_match_finder(min(level, 9)))
+        m = np.ascontiguousarray(m, dtype=np.uint32)
+        r = lib().m4g_brotli_encode_blocks(devices[0], a.ctypes.data if a.size else None, a.size, 1 << 16,
+                                           m.ctypes.data if m.size else None, off.ctypes.data, buf.ctypes.data, cap)
+        _check(r, "m4g_brotli_encode_blocks")
+        return buf[:r].tobytes()
     r = lib().m4g_brotli_compress_v2(level, device, a.ctypes.data if a.size else None, a.size, buf.ctypes.data, cap)
     _check(r, "m4g_brotli_compress_v2")
     if r < 0:

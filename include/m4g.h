@@ -519,6 +519,40 @@ int m4g_bargain_last_timings(const m4g_bargain *g, float *ms, int cap);
 int64_t m4g_bargain_find_blocks(const m4g_bargain_params *params, int device, const uint8_t *src,
                                 size_t n, m4g_match *out, size_t out_cap, uint64_t *block_off);
 
+/* Replaces: matchfinder.Bargain1 / Bargain2 / Bargain3 AS A matchfinder.MatchFinder
+ * (bargain1.go:33-38 Reset, :38-208 FindMatches; writer.go:142-150 plugs
+ * &Bargain1{MaxDistance: 1 << 20} ... into matchfinder.Writer, which then calls
+ * FindMatches block after block, matchfinder.go:81-87).  A handle carries the
+ * stream from call to call: m4g_bargain_ctx_find_blocks(ctx, block, n, ...)
+ * with n <= block_size is FindMatches(dst[:0], block); with a longer src it is
+ * that call for every consecutive block of params->block_size bytes (the
+ * throughput form: one wavefront per block, all blocks of the call in one
+ * launch), block b's Matches in out[block_off[b] .. block_off[b + 1]).
+ * m4g_bargain_ctx_reset = Reset.  The blocks of a stream must have the shape
+ * matchfinder.Writer gives them: block_size bytes each, a shorter one only as
+ * the last before Reset (M4G_ERR_BAD_PARAM otherwise: the finder leaves the last
+ * 7 / 11 positions of every block out of its tables, bargain1.go:136-139, and
+ * the handle keeps no list of block ends).  Between calls the handle keeps
+ * the stream's last whole blocks, MaxDistance bytes or more, on the host and
+ * re-inserts them (without searching them) in front of the new blocks: a
+ * history slide (bargain1.go:66-80) leaves no other trace.  Safe out_cap:
+ * n / 3 + 2 * blocks + 8.  Returns the number of Matches, -(needed +
+ * M4G_STREAM_NEEDED_BIAS), or an M4G_ERR_*.  One thread at a time per handle. */
+typedef struct m4g_bargain_ctx m4g_bargain_ctx;
+int m4g_bargain_ctx_create(const m4g_bargain_params *params, int device, m4g_bargain_ctx **out);
+void m4g_bargain_ctx_destroy(m4g_bargain_ctx *ctx);
+int m4g_bargain_ctx_reset(m4g_bargain_ctx *ctx);
+int64_t m4g_bargain_ctx_find_blocks(m4g_bargain_ctx *ctx, const uint8_t *src, size_t n, m4g_match *out,
+                                    size_t out_cap, uint64_t *block_off /* nullable */);
+
+/* m4g_bargain_find_blocks with the stream's blocks spread over `devices`
+ * (protocol P1): every device gets a contiguous range of blocks
+ * and the whole blocks before it (MaxDistance bytes or more) as history; no
+ * device talks to another, the lists are joined in stream order on the host. */
+int64_t m4g_bargain_find_blocks_multi(const m4g_bargain_params *params, const int *devices, int ndevices,
+                                      const uint8_t *src, size_t n, m4g_match *out, size_t out_cap,
+                                      uint64_t *block_off);
+
 /* Replaces: brotli.NewWriterV2(dst, level) for levels 5-9 (writer.go:126-161) as a streaming handle: the returned
  * m4g_writer's m4g_writer_write / _close / _reset / _destroy are the Write / Close / Reset of the
  * matchfinder.Writer{Bargain1 | Bargain2{Skip} | Bargain2 | Bargain3, &Encoder{}, BlockSize 1 << 16} the reference

@@ -109,12 +109,47 @@ private:
 // is one wavefront's work, so the GPU form takes the whole stream: FindMatchesBlocks returns what the
 // FindMatches calls of matchfinder.Writer{MatchFinder: &BargainN{MaxDistance, Skip}, BlockSize} produce for
 // src (matchfinder.go:59-93), the Match list of block b in dst[blockOff[b] .. blockOff[b+1]).
-class Bargain {
+//
+// Bargain IS a MatchFinder (bargain1.go:33-38): FindMatches takes one block of the stream per call -- BlockSize
+// bytes each, a shorter one only as the last before Reset, which is what matchfinder.Writer{BlockSize} hands over --
+// and Reset starts a new stream (m4g_bargain_ctx_*: the handle keeps the stream's last MaxDistance bytes).
+class Bargain : public MatchFinder {
 public:
   int Variant = 1; // 1, 2, 3 = Bargain1, Bargain2, Bargain3
   int MaxDistance = 0;
   bool Skip = false;
+  size_t BlockSize = (size_t)1 << 16; // of the Writer this finder is plugged into
   int Device = 0;
+
+  ~Bargain() override { m4g_bargain_ctx_destroy(ctx_); }
+
+  std::vector<Match> &FindMatches(std::vector<Match> &dst, const uint8_t *src, size_t n) override {
+    std::vector<size_t> off;
+    return FindMatchesStream(dst, src, n, off);
+  }
+  void Reset() override {
+    if (ctx_) m4g_bargain_ctx_reset(ctx_);
+  }
+  // FindMatches for every consecutive block of BlockSize bytes of src, continuing the stream, in one launch
+  std::vector<Match> &FindMatchesStream(std::vector<Match> &dst, const uint8_t *src, size_t n, std::vector<size_t> &blockOff) {
+    if (!ctx_) {
+      m4g_bargain_params p{Variant, MaxDistance, Skip ? 1 : 0, (int32_t)BlockSize};
+      const int rc = m4g_bargain_ctx_create(&p, Device, &ctx_);
+      if (rc) throw std::runtime_error(std::string("m4g_bargain_ctx_create: ") + m4g_strerror(rc) + " (" + m4g_last_error() + ")");
+    }
+    const size_t nblocks = (n + BlockSize - 1) / BlockSize;
+    std::vector<m4g_match> buf(n / 3 + 2 * nblocks + 8);
+    std::vector<uint64_t> off(nblocks + 1, 0);
+    const int64_t r = m4g_bargain_ctx_find_blocks(ctx_, src, n, buf.data(), buf.size(), off.data());
+    if (r < 0)
+      throw std::runtime_error(std::string("m4g_bargain_ctx_find_blocks: ") + m4g_strerror((int)r) + " (" + m4g_last_error() + ")");
+    const size_t base = dst.size();
+    dst.reserve(base + (size_t)r);
+    for (int64_t k = 0; k < r; k++) dst.push_back(Match{buf[k].unmatched, buf[k].length, buf[k].distance});
+    blockOff.assign(nblocks + 1, base);
+    for (size_t b = 0; b <= nblocks; b++) blockOff[b] = base + (size_t)off[b];
+    return dst;
+  }
 
   std::vector<Match> &FindMatchesBlocks(std::vector<Match> &dst, const uint8_t *src, size_t n, size_t blockSize,
                                         std::vector<size_t> &blockOff) {
@@ -134,6 +169,9 @@ public:
     for (size_t b = 0; b <= nblocks; b++) blockOff[b] = base + (size_t)off[b];
     return dst;
   }
+
+private:
+  m4g_bargain_ctx *ctx_ = nullptr;
 };
 
 struct AutoReset : MatchFinder {

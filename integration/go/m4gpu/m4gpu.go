@@ -395,6 +395,99 @@ func BargainBlocks(data []byte, variant, maxDistance int, skip bool, blockSize i
 	return matches, off
 }
 
+// Bargain1, Bargain2 and Bargain3 have the exported fields of matchfinder.Bargain1 / Bargain2 / Bargain3
+// (bargain1.go:15-31: MaxDistance, Skip) and implement matchfinder.MatchFinder on the GPU (m4g_bargain_ctx_*), so
+//   &matchfinder.Writer{Dest: dst, MatchFinder: &m4gpu.Bargain1{MaxDistance: 1 << 20}, Encoder: &brotli.Encoder{}, BlockSize: 1 << 16}
+// is brotli.NewWriterV2(dst, 5) with its match finder replaced and nothing else changed (writer.go:142-156).
+// BlockSize must be the Writer's (0 = 1 << 16): the finder leaves the last bytes of every block out of its tables
+// (bargain1.go:136-139) and the handle learns the block ends from it.  A block shorter than BlockSize ends the
+// stream; Reset starts the next one.  One call is one wavefront's work: fast use is FindMatchesBlocks.
+type Bargain1 struct {
+	MaxDistance int
+	Skip        bool
+	BlockSize   int
+	Device      int
+	b           bargain
+}
+type Bargain2 struct {
+	MaxDistance int
+	Skip        bool
+	BlockSize   int
+	Device      int
+	b           bargain
+}
+type Bargain3 struct {
+	MaxDistance int
+	Skip        bool
+	BlockSize   int
+	Device      int
+	b           bargain
+}
+
+var (
+	_ matchfinder.MatchFinder = (*Bargain1)(nil)
+	_ matchfinder.MatchFinder = (*Bargain2)(nil)
+	_ matchfinder.MatchFinder = (*Bargain3)(nil)
+)
+
+type bargain struct {
+	ctx *C.m4g_bargain_ctx
+	raw []C.m4g_match
+}
+
+func (b *bargain) find(variant, maxDistance int, skip bool, blockSize, device int, dst []matchfinder.Match, src []byte) []matchfinder.Match {
+	if blockSize == 0 {
+		blockSize = 1 << 16
+	}
+	if b.ctx == nil {
+		p := C.m4g_bargain_params{variant: C.int32_t(variant), max_distance: C.int32_t(maxDistance), block_size: C.int32_t(blockSize)}
+		if skip {
+			p.skip = 1
+		}
+		if rc := C.m4g_bargain_ctx_create(&p, C.int(device), &b.ctx); rc != 0 {
+			fail("m4g_bargain_ctx_create", rc)
+		}
+		runtime.SetFinalizer(b, func(b *bargain) { C.m4g_bargain_ctx_destroy(b.ctx) })
+	}
+	if len(src) == 0 {
+		return dst
+	}
+	nb := (len(src) + blockSize - 1) / blockSize
+	if need := len(src)/3 + 2*nb + 8; len(b.raw) < need {
+		b.raw = make([]C.m4g_match, need)
+	}
+	n := C.m4g_bargain_ctx_find_blocks(b.ctx, (*C.uint8_t)(unsafe.Pointer(&src[0])), C.size_t(len(src)),
+		&b.raw[0], C.size_t(len(b.raw)), nil)
+	if n < 0 {
+		fail("m4g_bargain_ctx_find_blocks", C.int(n))
+	}
+	for i := 0; i < int(n); i++ {
+		m := b.raw[i]
+		dst = append(dst, matchfinder.Match{Unmatched: int(m.unmatched), Length: int(m.length), Distance: int(m.distance)})
+	}
+	return dst
+}
+
+func (b *bargain) reset() {
+	if b.ctx != nil {
+		C.m4g_bargain_ctx_reset(b.ctx)
+	}
+}
+
+// FindMatches implements matchfinder.MatchFinder (bargain1.go:38).
+func (q *Bargain1) FindMatches(dst []matchfinder.Match, src []byte) []matchfinder.Match {
+	return q.b.find(1, q.MaxDistance, q.Skip, q.BlockSize, q.Device, dst, src)
+}
+func (q *Bargain1) Reset() { q.b.reset() } // bargain1.go:33-36
+func (q *Bargain2) FindMatches(dst []matchfinder.Match, src []byte) []matchfinder.Match {
+	return q.b.find(2, q.MaxDistance, q.Skip, q.BlockSize, q.Device, dst, src)
+}
+func (q *Bargain2) Reset() { q.b.reset() }
+func (q *Bargain3) FindMatches(dst []matchfinder.Match, src []byte) []matchfinder.Match {
+	return q.b.find(3, q.MaxDistance, q.Skip, q.BlockSize, q.Device, dst, src)
+}
+func (q *Bargain3) Reset() { q.b.reset() }
+
 // CompressV2 is w := brotli.NewWriterV2(dst, level); w.Write(data); w.Close() for levels 5-9 (writer.go:126-161)
 // with match finder and encoder on the GPU; it returns the brotli stream.
 func CompressV2(data []byte, level int) []byte {

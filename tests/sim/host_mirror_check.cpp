@@ -105,6 +105,25 @@ int main() {
       }
     }
   }
+  // Bargain1 as a MatchFinder behind the Writer template: block-by-block FindMatches equals the whole-stream lists
+  {
+    matchfinder::Bargain bg;
+    bg.MaxDistance = 1 << 16;
+    bg.BlockSize = 8192;
+    std::vector<matchfinder::Match> whole, calls;
+    std::vector<size_t> boff;
+    bg.FindMatchesBlocks(whole, data.data(), data.size(), 8192, boff);
+    matchfinder::MatchFinder *mf = &bg;
+    for (size_t p = 0; p < data.size(); p += 8192) mf->FindMatches(calls, data.data() + p, std::min<size_t>(8192, data.size() - p));
+    bool same = whole.size() == calls.size();
+    for (size_t k = 0; same && k < whole.size(); k++)
+      same = whole[k].Unmatched == calls[k].Unmatched && whole[k].Length == calls[k].Length && whole[k].Distance == calls[k].Distance;
+    if (!same) {
+      std::puts("FAIL bargain (MatchFinder calls)");
+      return 1;
+    }
+    mf->Reset();
+  }
   // NewWriterV2(dst, 5) as a handle: ragged Writes and one Write give the same stream
   {
     Sink v1, v2;

@@ -193,3 +193,67 @@ def test_new_writer_v2_streaming_handle(level):
         w.Close()
         assert dst3.value() == oracle_writer_v2(blob, level)
         assert brotli_decompress(dst3.value(), len(blob)) == blob
+
+
+# ---- Bargain as a matchfinder.MatchFinder (m4g_bargain_ctx_*): FindMatches / Reset block after block ----------------
+class _Sink:
+    def __init__(self):
+        self.b = bytearray()
+
+    def write(self, p):
+        self.b += p
+
+
+@pytest.mark.parametrize("level", [5, 7, 9])
+def test_bargain_is_a_match_finder_behind_the_unchanged_writer(level):
+    """matchfinder.Writer{MatchFinder: Bargain on the GPU, Encoder: the restated brotli.Encoder, BlockSize 1 << 16}
+    -- the Writer restated in m4.Writer calls FindMatches once per block, as matchfinder.go:81-87 does -- gives the
+    bytes of the restated NewWriterV2; then Reset and a second stream."""
+    kw = m4.writer_v2_match_finder(level)
+    data = open(OPTICKS, "rb").read()
+    mf = m4.Bargain(kw["variant"], kw["MaxDistance"], kw["Skip"], kw["BlockSize"])
+    for blob in (data, data[:1 << 16], data[:70001]):
+        dst = _Sink()
+        w = m4.Writer(dst, mf, OracleEncoder(), kw["BlockSize"])
+        w.Write(blob[:100000])
+        w.Write(blob[100000:])
+        w.Close()
+        assert bytes(dst.b) == oracle_writer_v2(blob, level), len(blob)
+        w.Reset(dst)  # MatchFinder.Reset + Encoder.Reset
+
+
+@pytest.mark.parametrize("variant,md,skip", [(1, 1 << 17, False), (2, 1 << 17, True), (3, 1 << 18, False), (1, 0, False)])
+def test_bargain_handle_over_a_stream_that_slides(variant, md, skip):
+    """Block-by-block calls and many-block calls on one handle, over a stream several times longer than
+    2 * MaxDistance (bargain1.go:66-80 slides again and again): Match for Match the sequential finder."""
+    data = text((3 << 20) + 1000, 21) if md else text(600000, 21)  # MaxDistance 0 = the default 1 << 16
+    bs = 1 << 16
+    want, woff = oracle_blocks(data, variant, md or (1 << 16), skip, bs)
+    mf = m4.Bargain(variant, md, skip, bs)
+    got, p = [], 0
+    rng = np.random.default_rng(variant)
+    while p < len(data):
+        k = int(rng.choice([1, 1, 2, 5, 9])) * bs  # FindMatches, or FindMatchesBlocks over k blocks
+        m, off = mf.find_matches_blocks(data[p:p + k])
+        got.append(m)
+        p += k
+    got = np.concatenate(got)
+    assert got.shape == want.shape and (got == want).all()
+    with pytest.raises(m4.M4GError):  # the stream's short last block has been seen: only Reset goes on
+        mf.find_matches_blocks(data[:bs])
+    mf.Reset()
+    m, off = mf.find_matches_blocks(data[:3 * bs])
+    assert (m == want[:int(woff[3])]).all() and (off == woff[:4]).all()
+
+
+@pytest.mark.parametrize("level", [5, 8, 9])
+def test_new_writer_v2_over_three_handles_on_one_card(level):
+    """One stream over several devices for the Bargain finders: the device list (0, 0, 0)."""
+    kw = m4.writer_v2_match_finder(level)
+    data = text((5 << 20) + 4321, 22)
+    want, woff = oracle_blocks(data, kw["variant"], kw["MaxDistance"], kw["Skip"], kw["BlockSize"])
+    for devices in ((0, 0, 0), (0,), (0, 0, 0, 0, 0, 0, 0)):
+        got, goff = m4.bargain_find_blocks_multi(data, devices, **kw)
+        assert np.array_equal(goff, woff) and (got == want).all(), devices
+    blob = open(OPTICKS, "rb").read()
+    assert m4.brotli_compress_v2(blob, level, devices=(0, 0, 0)) == oracle_writer_v2(blob, level)
