@@ -18,6 +18,8 @@ import zlib
 import numpy as np
 import pytest
 
+from brotli_amd import synth
+
 from tests import cases
 from tests.oracle_lib import (OracleFlateEncoder, OracleM4, flate_compress, flate_generate, flate_m4_params,
                               flate_statistics, lib)
@@ -175,6 +177,10 @@ def test_match_limits_are_the_reference_panics():
     big = bytes(40000) + b"y"
     with pytest.raises(ValueError):
         OracleFlateEncoder().Encode(big, np.array([[1, 100, 1], [32900, 10, 32800], [6990, 0, 0]], dtype=np.uint32), True)
+    # the whole Writer: a block in the middle of the stream with a match the format cannot hold
+    data = synth.text(70000, 1) + b"a" * 70000 + synth.text(70000, 2)
+    with pytest.raises(ValueError):
+        flate_compress(OracleM4(**flate_m4_params(5)), data, 1 << 16)
     lit, off = flate_statistics(b"abcabcabc", np.array([[3, 6, 3]], dtype=np.uint32))
     assert lit[ord("a")] == lit[ord("b")] == lit[ord("c")] == 1 and lit[257 + 3] == 1 and off[2] == 1
     assert lit.sum() == 4 and off.sum() == 1

@@ -64,6 +64,11 @@ def test_encode_edge_chunks():
     chunks = [e["text_1000"], b"", e["short3"], e["len8"], e["kat_run40"], e["zeros_70k"], e["random_20k"],
               bytes(rng.integers(0, 256, 200000, dtype=np.uint8)), e["lowent_50k"], e["period_mix"], b"ab" * 40,
               b"abcd" * 50, e["log_65536"]] + [v[1] for v in hand_kats().values() if v[0] == dict()]
+    # alphabets of 2..4 literals in every order of frequencies: the 'simple' prefix codes with their depth sort and
+    # tree-select bit (tests/test_oracle.py: test_simple_prefix_codes_of_two_to_four_symbols_decode)
+    for counts in ((9, 1), (1, 9), (5, 3, 1), (1, 3, 5), (8, 4, 2, 1), (1, 2, 4, 8), (3, 3, 3, 3), (1, 1, 1, 6), (2, 9, 1, 3)):
+        raw = b"".join(bytes([s]) * (c * 13) for s, c in zip(b"qcxk", counts))
+        chunks.append(bytes(rng.permutation(np.frombuffer(raw, dtype=np.uint8))))
     _check(chunks, PARAMS_G)
     _check([b""], PARAMS_G)
     _check([b"", b"x"], PARAMS_G)

@@ -297,3 +297,32 @@ def test_oracle_branch_coverage():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "oracle_coverage.py"), "--check"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+
+
+def _literal_only(data: bytes):
+    return np.array([[len(data), 0, 0]], dtype=np.uint32)
+
+
+@pytest.mark.parametrize("counts", [(9, 1), (1, 9), (5, 3, 1), (1, 3, 5), (8, 4, 2, 1), (1, 2, 4, 8), (3, 3, 3, 3),
+                                    (1, 1, 1, 6), (6, 1, 1, 1), (2, 9, 1, 3)],
+                         ids=lambda c: "-".join(map(str, c)))
+def test_simple_prefix_codes_of_two_to_four_symbols_decode(counts):
+    """buildAndStoreHuffmanTreeFast (brotli_bit_stream.go:637-741) writes alphabets of at most 4 used symbols as a
+    'simple' prefix code: the symbols sorted by depth and, for four, the tree-select bit.  Literal-only blocks
+    over 2..4 distinct bytes with every order of frequencies; the system decoder must give the bytes back."""
+    rng = np.random.default_rng(sum(counts))
+    syms = b"qcxk"[:len(counts)]
+    data = bytearray()
+    for s, c in zip(syms, counts):
+        data += bytes([s]) * (c * 13)
+    data = bytes(rng.permutation(np.frombuffer(bytes(data), dtype=np.uint8)))
+    out = OracleEncoder().Encode(data, _literal_only(data), True)
+    assert brotli_decompress(out, len(data)) == data
+
+
+def test_meta_block_longer_than_a_mebibyte_decodes():
+    """storeMetaBlockHeaderBW (compress_fragment_two_pass.go:222-241): MLEN above 1 << 20 takes six nibbles."""
+    data = synth.text((1 << 20) + 70000, 3)
+    m = OracleM4(MaxDistance=1 << 20, DistanceBitCost=66)
+    out = OracleEncoder().Encode(data, m.FindMatches(data), True)
+    assert brotli_decompress(out, len(data)) == data
