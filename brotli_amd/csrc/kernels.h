@@ -547,7 +547,7 @@ constexpr int K3_THREADS = 64;
 #define M4G_K3_W 16
 #endif
 #ifndef M4G_K3_MINWAVES
-#define M4G_K3_MINWAVES 1
+#define M4G_K3_MINWAVES 4
 #endif
 constexpr int K3_W = M4G_K3_W;
 constexpr int K3_BACK = 16;
@@ -703,6 +703,7 @@ __device__ __forceinline__ uint64_t k3_wave_of_block(uint32_t b, uint32_t nblock
 #endif
 constexpr int32_t K3_EXT_LIMIT = M4G_K3_EXT_LIMIT;
 
+template <bool LIGHT>
 __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     const uint8_t *__restrict__ src_base, uint64_t src_total,
     const uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, Rec *__restrict__ rs,
@@ -747,11 +748,10 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (row_on) {
       M.w0 = w0;
-#ifdef M4G_K3_NOLIGHT
-      parse_range<false>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
-#else
-      parse_range<false, true>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
-#endif
+      // (the LIGHT filter pays only without chain walks: with ChainLength > 0 every entry within MaxDistance is an
+      // event, and params D measured 158 ms per GiB with it against 144 without)
+      // (two instantiations, chosen at the launch: both in one kernel cost it its fourth wave per SIMD)
+      parse_range<false, LIGHT>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
       aborted = len_eff < len && (S.error & kStateTouchedEnd);
     }
   }
@@ -871,6 +871,23 @@ struct FastMem {
 // (the give-up shortcut of the StagedMem overload above)
 __device__ __forceinline__ int32_t extend_fwd(const FastMem &M, int32_t len, int32_t i, int32_t j) {
   int32_t run = 0;
+  // 32 bytes per step while they fit: the four loads of each stream are in flight together (a parked lane's
+  // match is usually a long one -- 48-byte record bodies in log data -- and every step is a far round trip)
+  while (j + 32 < len) {
+    const uint64_t a0 = M.far64(i), a1 = M.far64(i + 8), a2 = M.far64(i + 16), a3 = M.far64(i + 24);
+    const uint64_t b0 = M.far64(j), b1 = M.far64(j + 8), b2 = M.far64(j + 16), b3 = M.far64(j + 24);
+    if (a0 != b0) return j + (int32_t)(__builtin_ctzll(a0 ^ b0) >> 3);
+    if (a1 != b1) return j + 8 + (int32_t)(__builtin_ctzll(a1 ^ b1) >> 3);
+    if (a2 != b2) return j + 16 + (int32_t)(__builtin_ctzll(a2 ^ b2) >> 3);
+    if (a3 != b3) return j + 24 + (int32_t)(__builtin_ctzll(a3 ^ b3) >> 3);
+    i += 32;
+    j += 32;
+    run += 32;
+    if (run == 256 && M.give_up_at > 0 && j + 16 < M.give_up_at) {
+      const int32_t d = M.give_up_at - 8 - j;
+      if (M.far64(i + d) == M.far64(j + d)) return M.give_up_at;
+    }
+  }
   while (j + 8 < len) {
     const uint64_t a = M.ld64(i), b = M.ld64(j);
     if (a != b) return j + (int32_t)(__builtin_ctzll(a ^ b) >> 3);

@@ -200,7 +200,8 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
   // Plans of a GiB and more have lanes to spare (2^19 sub-blocks of 2 KiB): longer sub-blocks mean fewer stitches
   // and less compaction (measured, 4096 x 1 MiB of text: K3 32.5 -> 31.6 ms, K4 2.6 -> 2.0; at 256 chunks the
   // inputs that defeat the speculation lose up to 25 %, so smaller plans keep 1 KiB).
-  if (!min_lanes && !std::getenv("M4G_SUB_BLOCK") && max_jobs * max_bytes >= ((size_t)1 << 30) && max_bytes >= ((size_t)1 << 17))
+  if (!min_lanes && !std::getenv("M4G_SUB_BLOCK") && p.chain_length == 0 && max_jobs * max_bytes >= ((size_t)1 << 30) &&
+      max_bytes >= ((size_t)1 << 17)) // (chain walks are latency bound and want every lane they can get: params D 158 -> 184 ms per GiB)
     w.L.sub_block = 2 * kDefaultSubBlock;
   if (min_lanes && !std::getenv("M4G_SUB_BLOCK")) {
     int sub = 64;
@@ -315,8 +316,11 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
   if (P.chain_length == 0 && w.L.kmax % K3_THREADS == 0 && !k3a_slow)
     hipLaunchKernelGGL(k3a_fast, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
                        w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
+  else if (P.chain_length == 0)
+    hipLaunchKernelGGL(k3a_spec<true>, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
+                       w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
   else
-    hipLaunchKernelGGL(k3a_spec, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
+    hipLaunchKernelGGL(k3a_spec<false>, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
                        w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
   HIP_TRY(hipGetLastError());
   if (w.L.kmax > 1) {
@@ -1607,7 +1611,7 @@ int64_t batch_one_device_pipelined(const m4g_params *params, const Params &p, co
   if (err)
     result = status_from_error_word(err);
   else if (run > out_cap)
-    result = -(int64_t)run;
+    result = -(int64_t)(run + M4G_STREAM_NEEDED_BIAS);
   else if (histos)
     PIPE_TRY(hipMemcpyAsync(histos, P.d_histos, nchunks * sizeof(m4g_histo), hipMemcpyDeviceToHost, P.st_out));
   PIPE_TRY(hipStreamSynchronize(P.st_out));
@@ -2069,7 +2073,7 @@ extern "C" int64_t m4g_hostbatch_run(m4g_hostbatch *h, const uint8_t *base, cons
     if (run <= out_cap && histos)
       HIP_TRY(hipMemcpyAsync(histos, L.d_histos, nchunks * sizeof(m4g_histo), hipMemcpyDeviceToHost, L.st_out));
     HIP_TRY(hipStreamSynchronize(L.st_out));
-    return run > out_cap ? -(int64_t)run : (int64_t)M4G_OK;
+    return run > out_cap ? -(int64_t)(run + M4G_STREAM_NEEDED_BIAS) : (int64_t)M4G_OK;
   }
   // several devices: global offsets in chunk order, then every lane sends its lists to their places
   uint64_t run = 0;

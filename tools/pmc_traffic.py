@@ -15,7 +15,7 @@ import sqlite3
 import sys
 
 STAGES = {"k1_chain_build": ["k1_chain_build", "k1x_chain_build", "k1p_partition", "k1c_consume"],
-          "k3_parse": ["k3a_spec", "k3b_stitch", "k3c_validate"],
+          "k3_parse": ["k3a_spec", "k3a_fast", "k3b_stitch", "k3c_validate"],
           "k4_compact": ["k4_scan_counts", "k4_compact"],
           # (the histogram-only instantiation: a run with the gpu_encode leg also holds k5_histograms<true>)
           "k5_histograms": ["k5_histogramsILb0", "k5_histograms<false>", "k5b_long_literals"]}
