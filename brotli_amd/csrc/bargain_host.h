@@ -281,7 +281,7 @@ int64_t bargain_run_impl(m4g_bargain *g, const uint8_t *d_src, const uint64_t *c
                        (uint32_t)nb, g->d_bc, g->d_wld, g->d_wc, g->ws_stride, g->d_stage, g->stage_cap, g->d_counts, g->d.P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(g->ev[3], st));
-  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, g->d_counts, g->d_off, (int)nb);
+  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, g->d_counts, g->d_off, (int)nb, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(g->h_total, g->d_off + nb, 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -1470,12 +1470,14 @@ __global__ __launch_bounds__(64) void k3c_validate(
 // ---------------------------------------------------------------------------
 // K4: exclusive prefix sum of counts (single workgroup) and compaction.
 // ---------------------------------------------------------------------------
+// carry_in: the jobs continue a list whose length so far an earlier launch left in out_off[0]
+// (the groups of a plan in its worst-case layout, m4g.hip run_batch_pipeline).
 __global__ __launch_bounds__(1024) void k4_scan_counts(
-    const uint32_t *__restrict__ counts, uint64_t *__restrict__ out_off, int njobs) {
+    const uint32_t *__restrict__ counts, uint64_t *__restrict__ out_off, int njobs, int carry_in) {
   __shared__ uint64_t wsum[16];
   __shared__ uint64_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) carry_s = 0;
+  if (tid == 0) carry_s = carry_in ? out_off[0] : 0;
   __syncthreads();
   for (int base = 0; base < njobs; base += 1024) {
     int j = base + tid;
@@ -1520,7 +1522,8 @@ __global__ __launch_bounds__(K4_THREADS) void k4_compact(
     const Rec *__restrict__ rs, const Rec *__restrict__ st, const Job *__restrict__ jobs,
     const BlockDesc *__restrict__ desc, const uint64_t *__restrict__ out_off,
     uint32_t *__restrict__ out /* 3 words per match */, uint64_t out_cap, int njobs, SpecLayout L,
-    LongRun *__restrict__ long_runs /* nullable */, uint32_t *__restrict__ n_long_runs, uint32_t long_cap) {
+    LongRun *__restrict__ long_runs /* nullable */, uint32_t *__restrict__ n_long_runs, uint32_t long_cap,
+    uint32_t job_base /* index of jobs[0] in the batch (LongRun.job counts from the batch's first job) */) {
   const uint64_t t = (uint64_t)blockIdx.x * (K4_THREADS / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const uint32_t job = (uint32_t)(t / L.kmax), k = (uint32_t)(t % L.kmax);
@@ -1543,7 +1546,7 @@ __global__ __launch_bounds__(K4_THREADS) void k4_compact(
     dst[2] = v.z;
     if (v.x >= K5_HUGE && long_runs) {
       const uint32_t s = atomicAdd(n_long_runs, 1u);
-      if (s < long_cap) long_runs[s] = LongRun{job, v.w & ~kRecFlushBit, v.x, 0};
+      if (s < long_cap) long_runs[s] = LongRun{job_base + job, v.w & ~kRecFlushBit, v.x, 0};
     }
   }
 }
@@ -1650,7 +1653,11 @@ template <bool CODES>
 __global__ __launch_bounds__(K5_THREADS) void k5_histograms(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ matches /* 3 words each */,
     const Job *__restrict__ jobs, const uint64_t *__restrict__ out_off, uint64_t out_cap,
-    uint32_t *__restrict__ histos /* 1024 u32 per job */, CodeRec *__restrict__ codes) {
+    uint32_t *__restrict__ histos /* 1024 u32 per job */, CodeRec *__restrict__ codes,
+    const uint32_t *__restrict__ errors /* nullable: the error word of the parse that made the lists */) {
+  // A parse that dropped records (error bit 1: a compact plan's slots overflowed) leaves holes in the lists;
+  // what is in them must not be used as lengths and positions.  The run is repeated (m4g.hip, batch_settle).
+  if (errors && (errors[0] & 2u)) return;
   __shared__ uint32_t lit[K5_WAVES][256];
   __shared__ uint32_t cmd[704];
   __shared__ uint32_t dst[64];
@@ -1839,7 +1846,8 @@ __global__ __launch_bounds__(K5B_THREADS) void k5b_long_literals(
     const uint8_t *__restrict__ src_base, const Job *__restrict__ jobs,
     const LongRun *__restrict__ long_runs, const uint32_t *__restrict__ n_long_runs,
     uint32_t long_cap, uint32_t segs_per_run, const uint64_t *__restrict__ out_off, uint64_t out_cap,
-    uint32_t *__restrict__ histos) {
+    uint32_t *__restrict__ histos, const uint32_t *__restrict__ errors /* nullable, as in k5_histograms */) {
+  if (errors && (errors[0] & 2u)) return;
   __shared__ uint32_t lit[K5B_THREADS / 64][256];
   const int tid = threadIdx.x, wid = tid >> 6;
   const uint32_t nruns = min(*n_long_runs, long_cap);

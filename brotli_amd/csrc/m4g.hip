@@ -161,15 +161,32 @@ struct SpecWork {
   Rec *rs = nullptr, *st = nullptr;
   ParseState *E = nullptr, *Tout = nullptr;
   BlockDesc *desc = nullptr;
+  // Compact plans (spec_alloc's `compact`): RS and ST are two halves of ONE allocation, sized for the record
+  // density inputs have in practice instead of the densest a parse can emit; a run that overflows a slot is
+  // repeated in the worst-case layout (spec_use_worst), which holds group_jobs jobs at a time.
+  bool arena = false;      // st points into the allocation of rs
+  size_t arena_recs = 0;   // records that allocation holds
+  uint32_t slot_worst = 0; // records a parse can emit per sub-block at most
+  size_t group_jobs = 0;   // K3 + K4 run over this many jobs at a time (0: all at once)
+  size_t bytes = 0;        // device memory held
+  bool compact() const { return arena && L.slot < slot_worst; }
 };
 
 void spec_free(SpecWork &w) {
   (void)hipFree(w.rs);
-  (void)hipFree(w.st);
+  if (!w.arena) (void)hipFree(w.st);
   (void)hipFree(w.E);
   (void)hipFree(w.Tout);
   (void)hipFree(w.desc);
   w = SpecWork{};
+}
+
+// The sticky switch of a compact plan to slots no input can overflow: the same allocation then holds the
+// records of group_jobs jobs, and run_batch_pipeline parses and compacts the batch group after group.
+void spec_use_worst(SpecWork &w) {
+  w.L.slot = w.slot_worst;
+  w.group_jobs = std::max<size_t>(1, w.arena_recs / (2 * (size_t)w.L.kmax * w.slot_worst));
+  w.st = w.rs + w.group_jobs * w.L.kmax * w.slot_worst;
 }
 
 constexpr int kDefaultSubBlock = 1024;
@@ -194,7 +211,8 @@ int sub_block_size() {
 // min_lanes > 0 (one job per launch: the streaming handle): sub-blocks small enough that the job
 // spreads over at least that many lanes -- a 64 KiB block parsed by 64 lanes of 1 KiB each is one
 // wave walking 64 epochs in a row (1.4 ms per call); in 128-byte sub-blocks it takes 0.37 ms, in 64-byte ones 0.27.
-int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, size_t min_lanes = 0) {
+int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, size_t min_lanes = 0,
+               bool compact = false, size_t min_arena_bytes = 0) {
   spec_free(w);
   w.L.sub_block = sub_block_size();
   // Plans of a GiB and more have lanes to spare (2^19 sub-blocks of 2 KiB): longer sub-blocks mean fewer stitches
@@ -214,18 +232,41 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
   // records a parse can emit while walking one sub-block: the matches are
   // disjoint and at least min_length long, plus the pending ones at entry and
   // the tail records of the last block.
-  w.L.slot = (uint32_t)((size_t)w.L.sub_block / (size_t)p.min_length + 18);
+  w.slot_worst = w.L.slot = (uint32_t)((size_t)w.L.sub_block / (size_t)p.min_length + 18);
   w.blocks = max_jobs * w.L.kmax;
-  const size_t nrec = w.blocks * w.L.slot;
-  if (hipMalloc(&w.rs, nrec * sizeof(Rec)) != hipSuccess ||
-      hipMalloc(&w.st, nrec * sizeof(Rec)) != hipSuccess ||
-      hipMalloc(&w.E, w.blocks * sizeof(ParseState)) != hipSuccess ||
+  size_t nrec = w.blocks * w.L.slot;
+  hipError_t e = hipSuccess;
+  if (compact) {
+    // One record per 8 positions: what the slots have to hold in practice (records per KiB, measured with the
+    // oracle on 1 MiB: text 66, binary log 32, random bytes of 2 / 3 / 4 symbols 118 / 109 / 90, 4-byte words
+    // without separators 124; the bound above is 256 + 18 per KiB).  Inputs beyond that exist (ChainLength 8 with
+    // HashLen 5 on 4 to 10 symbols: 150 - 180 per KiB): their first run overflows, is detected (error bit 1) and
+    // repeated in the worst-case layout, which the plan then keeps.  The allocation always holds one job in that
+    // layout, and the keys of the split K1 (min_arena_bytes), which are dead before K3 starts.
+    const uint32_t slot_c = std::min<uint32_t>(w.slot_worst, (uint32_t)w.L.sub_block / 8 + 2);
+    size_t recs = std::max(2 * w.blocks * slot_c, 2 * (size_t)w.L.kmax * w.slot_worst);
+    recs = std::max(recs, (min_arena_bytes + sizeof(Rec) - 1) / sizeof(Rec));
+    if (recs < 2 * nrec) {
+      w.arena = true;
+      w.arena_recs = recs;
+      w.L.slot = slot_c;
+      nrec = w.blocks * slot_c;
+      if ((e = hipMalloc(&w.rs, recs * sizeof(Rec))) == hipSuccess) w.st = w.rs + nrec;
+      w.bytes += recs * sizeof(Rec);
+    }
+  }
+  if (!w.arena) {
+    if ((e = hipMalloc(&w.rs, nrec * sizeof(Rec))) == hipSuccess) e = hipMalloc(&w.st, nrec * sizeof(Rec));
+    w.bytes += 2 * nrec * sizeof(Rec);
+  }
+  if (e != hipSuccess || hipMalloc(&w.E, w.blocks * sizeof(ParseState)) != hipSuccess ||
       hipMalloc(&w.Tout, w.blocks * sizeof(ParseState)) != hipSuccess ||
       hipMalloc(&w.desc, w.blocks * sizeof(BlockDesc)) != hipSuccess) {
     (void)hipGetLastError();
     spec_free(w);
     return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the parse workspace failed");
   }
+  w.bytes += w.blocks * (2 * sizeof(ParseState) + sizeof(BlockDesc));
   return M4G_OK;
 }
 
@@ -347,14 +388,15 @@ int launch_find(const Params &p, const uint8_t *d_src, uint64_t src_total, uint3
 // K4 for jobs already through launch_find: offsets, then the records.
 int launch_compact(const SpecWork &w, const Job *d_jobs, const uint32_t *d_counts, int njobs,
                    uint64_t *d_out_off, m4g_match *d_out, size_t out_cap, hipStream_t st,
-                   LongRun *d_long_runs = nullptr, uint32_t *d_n_long = nullptr, uint32_t long_cap = 0) {
-  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, d_counts, d_out_off, njobs);
+                   LongRun *d_long_runs = nullptr, uint32_t *d_n_long = nullptr, uint32_t long_cap = 0,
+                   uint32_t job_base = 0 /* > 0: the jobs continue the list whose length is in d_out_off[0] */) {
+  hipLaunchKernelGGL(k4_scan_counts, dim3(1), dim3(1024), 0, st, d_counts, d_out_off, njobs, job_base ? 1 : 0);
   HIP_TRY(hipGetLastError());
   const uint64_t waves = (uint64_t)njobs * w.L.kmax;
   const unsigned g4 = (unsigned)((waves + (K4_THREADS / 64) - 1) / (K4_THREADS / 64));
   hipLaunchKernelGGL(k4_compact, dim3(g4), dim3(K4_THREADS), 0, st, w.rs, w.st, d_jobs, w.desc,
                      d_out_off, reinterpret_cast<uint32_t *>(d_out), (uint64_t)out_cap, njobs, w.L,
-                     d_long_runs, d_n_long, long_cap);
+                     d_long_runs, d_n_long, long_cap, job_base);
   HIP_TRY(hipGetLastError());
   return M4G_OK;
 }
@@ -488,6 +530,18 @@ struct m4g_batch {
   hipStream_t last_stream = nullptr;
   EncBuffers enc;                  // m4g_batch_encode: its device buffers, grown on demand
   FlateBuffers flate;              // m4g_batch_flate_encode: its device buffers, grown on demand
+  size_t bytes = 0;                // device memory of the plan (without enc / flate)
+  struct LastRun {                 // the arguments of the most recent run: batch_settle repeats it after a slot overflow
+    const uint8_t *d_src = nullptr;
+    uint64_t src_total = 0;
+    int njobs = 0;
+    m4g_match *d_out = nullptr;
+    uint64_t *d_out_off = nullptr;
+    size_t out_cap = 0;
+    m4g_histo *d_histos = nullptr;
+    m4g_code *d_codes = nullptr;
+  } last;
+  uint32_t reruns = 0;             // runs repeated because a slot overflowed (at most one per plan: the switch is sticky)
 };
 
 extern "C" void m4g_batch_destroy(m4g_batch *b) {
@@ -511,8 +565,22 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   delete b;
 }
 
+namespace {
+int batch_create(const m4g_params *params, int device, size_t max_chunks, size_t max_chunk_bytes, bool compact,
+                 m4g_batch **out);
+}
+// The plan a caller creates keeps its records in compact slots (spec_alloc; M4G_SLOTS=worst in the environment:
+// the worst-case layout from the start); the host-memory entry points below create theirs (one per slice, small)
+// in the worst-case layout, since they read the error word of several runs in flight themselves.
 extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max_chunks,
                                 size_t max_chunk_bytes, m4g_batch **out) {
+  const char *e = std::getenv("M4G_SLOTS");
+  return batch_create(params, device, max_chunks, max_chunk_bytes, !(e && std::strcmp(e, "worst") == 0), out);
+}
+
+namespace {
+int batch_create(const m4g_params *params, int device, size_t max_chunks, size_t max_chunk_bytes, bool compact,
+                 m4g_batch **out) {
   if (!out) return fail(M4G_ERR_BAD_PARAM, "out is NULL");
   *out = nullptr;
   Params p;
@@ -532,42 +600,45 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   b->max_chunks = max_chunks;
   b->max_chunk_bytes = max_chunk_bytes;
   const size_t nbytes = max_chunks * max_chunk_bytes;
-  if ((rc = spec_alloc(b->W.w, p, max_chunks, max_chunk_bytes))) {
+  const size_t chain_bytes = (nbytes + 16 * max_chunks) * 4;
+  b->W.split.kt_max = kp_tiles((uint32_t)max_chunk_bytes);
+  const bool split = p.table_bits >= 4 && p.table_bits <= kMaxPartBits + 2 && b->W.split.kt_max > 0;
+  // (the keys of the split K1 live in the record slots: k1c reads up to 127 words past a bin)
+  if ((rc = spec_alloc(b->W.w, p, max_chunks, max_chunk_bytes, 0, compact, split ? chain_bytes + 4096 : 0))) {
     m4g_batch_destroy(b);
     return rc;
   }
   hipError_t e;
-  if ((e = hipMalloc(&b->W.d_chain, (nbytes + 16 * max_chunks) * 4 + 4096)) != hipSuccess ||
+  b->W.long_cap = (uint32_t)std::min<size_t>(max_chunks * (max_chunk_bytes / K5_HUGE + 1), 1u << 28);
+  if ((e = hipMalloc(&b->W.d_chain, chain_bytes + 4096)) != hipSuccess ||
       (e = hipMalloc(&b->W.d_counts, max_chunks * 4)) != hipSuccess ||
       (e = hipMalloc(&b->W.d_errors, 64)) != hipSuccess ||
       (e = hipMalloc(&b->W.d_jobs, max_chunks * sizeof(Job))) != hipSuccess ||
       (e = hipHostMalloc(reinterpret_cast<void **>(&b->h_jobs), max_chunks * sizeof(Job), hipHostMallocDefault)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&b->ev_jobs, hipEventDisableTiming)) != hipSuccess ||
-      (e = hipMalloc(&b->W.d_long_runs, (b->W.long_cap = (uint32_t)std::min<size_t>(
-                                             max_chunks * (max_chunk_bytes / K5_HUGE + 1), 1u << 28)) *
-                                            sizeof(LongRun))) != hipSuccess) {
+      (e = hipMalloc(&b->W.d_long_runs, b->W.long_cap * sizeof(LongRun))) != hipSuccess) {
     std::string msg = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
     m4g_batch_destroy(b);
     return fail(M4G_ERR_NO_MEMORY, msg);
   }
-  { // buffers of the split K1 (the test hook may switch variants later)
-    const size_t chain_bytes = (nbytes + 16 * max_chunks) * 4;
-    b->W.split.kt_max = kp_tiles((uint32_t)max_chunk_bytes);
-    if (p.table_bits >= 4 && p.table_bits <= kMaxPartBits + 2 && b->W.split.kt_max > 0) {
-      const size_t rs_bytes = b->W.w.blocks * b->W.w.L.slot * sizeof(Rec);
-      if (rs_bytes >= chain_bytes + 4096) { // (k1c reads up to 127 words past a bin)
-        b->W.split.keys = reinterpret_cast<uint32_t *>(b->W.w.rs);
-      } else if ((e = hipMalloc(&b->W.keys_own, chain_bytes + 4096)) == hipSuccess) {
-        b->W.split.keys = b->W.keys_own;
-      }
-      if (e == hipSuccess)
-        e = hipMalloc(&b->W.split.hdr, max_chunks * (size_t)b->W.split.kt_max * KP_BINS * 4);
-      if (e != hipSuccess) {
-        std::string msg = std::string("hipMalloc K1 key workspace: ") + hipGetErrorString(e);
-        m4g_batch_destroy(b);
-        return fail(M4G_ERR_NO_MEMORY, msg);
-      }
+  b->bytes = b->W.w.bytes + chain_bytes + 4096 + max_chunks * (4 + sizeof(Job)) + 64 + b->W.long_cap * sizeof(LongRun);
+  if (split) { // buffers of the split K1 (the test hook may switch variants later)
+    const SpecWork &w = b->W.w;
+    const size_t rs_bytes = (w.arena ? w.arena_recs : w.blocks * w.L.slot) * sizeof(Rec);
+    if (rs_bytes >= chain_bytes + 4096) {
+      b->W.split.keys = reinterpret_cast<uint32_t *>(w.rs);
+    } else if ((e = hipMalloc(&b->W.keys_own, chain_bytes + 4096)) == hipSuccess) {
+      b->W.split.keys = b->W.keys_own;
+      b->bytes += chain_bytes + 4096;
     }
+    const size_t hdr_bytes = max_chunks * (size_t)b->W.split.kt_max * KP_BINS * 4;
+    if (e == hipSuccess) e = hipMalloc(&b->W.split.hdr, hdr_bytes);
+    if (e != hipSuccess) {
+      std::string msg = std::string("hipMalloc K1 key workspace: ") + hipGetErrorString(e);
+      m4g_batch_destroy(b);
+      return fail(M4G_ERR_NO_MEMORY, msg);
+    }
+    b->bytes += hdr_bytes;
   }
   for (auto &ev : b->ev) {
     if (hipEventCreate(&ev) != hipSuccess) {
@@ -578,6 +649,7 @@ extern "C" int m4g_batch_create(const m4g_params *params, int device, size_t max
   *out = b;
   return M4G_OK;
 }
+} // namespace
 
 extern "C" void m4g_batch_set_timing(m4g_batch *b, int enabled) {
   if (b) b->timing = enabled != 0;
@@ -618,14 +690,23 @@ int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, co
                        m4g_histo *d_histos, m4g_code *d_codes, hipStream_t st, hipEvent_t *ev) {
   HIP_TRY(hipMemsetAsync(W.d_errors, 0, 64, st));
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
-  int rc = launch_find(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, W.w, W.d_counts,
-                       W.d_errors, st, ev ? ev[1] : nullptr, &W.split);
+  int rc = launch_k1(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, st, nullptr, nullptr, &W.split);
   if (rc) return rc;
-  if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+  if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   uint32_t *n_long = W.d_errors + 8; // zeroed with d_errors above
-  if ((rc = launch_compact(W.w, W.d_jobs, W.d_counts, njobs, d_out_off, d_out, out_cap, st,
-                           d_histos ? W.d_long_runs : nullptr, n_long, W.long_cap)))
-    return rc;
+  // K3 + K4, for all jobs at once -- or, for a compact plan after its switch to the worst-case layout, group after
+  // group in the same record slots (a group's records are compacted before the next group's parse overwrites them;
+  // ev[2] then stands after the last parse, so the earlier groups' compaction counts as parse time)
+  const int group = W.w.group_jobs ? (int)std::min<size_t>(W.w.group_jobs, (size_t)njobs) : njobs;
+  for (int j0 = 0; j0 < njobs; j0 += group) {
+    const int nj = std::min(group, njobs - j0);
+    if ((rc = launch_parse(p, d_src, src_total, W.d_chain, W.d_jobs + j0, nj, W.w, W.d_counts + j0, W.d_errors, st)))
+      return rc;
+    if (ev && j0 + nj >= njobs) HIP_TRY(hipEventRecord(ev[2], st));
+    if ((rc = launch_compact(W.w, W.d_jobs + j0, W.d_counts + j0, nj, d_out_off + j0, d_out, out_cap, st,
+                             d_histos ? W.d_long_runs : nullptr, n_long, W.long_cap, (uint32_t)j0)))
+      return rc;
+  }
   if (ev) HIP_TRY(hipEventRecord(ev[3], st));
 
   if (d_histos) {
@@ -635,18 +716,18 @@ int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, co
       hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
                          reinterpret_cast<const uint32_t *>(d_out), W.d_jobs, d_out_off,
                          (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
-                         reinterpret_cast<CodeRec *>(d_codes));
+                         reinterpret_cast<CodeRec *>(d_codes), W.d_errors);
     else
       hipLaunchKernelGGL(k5_histograms<false>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
                          reinterpret_cast<const uint32_t *>(d_out), W.d_jobs, d_out_off,
                          (uint64_t)out_cap, reinterpret_cast<uint32_t *>(d_histos),
-                         static_cast<CodeRec *>(nullptr));
+                         static_cast<CodeRec *>(nullptr), W.d_errors);
     HIP_TRY(hipGetLastError());
     // the literal runs K4 set aside (none on compressible input: the grid finds an empty list)
     const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
     hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, st, d_src, W.d_jobs,
                        W.d_long_runs, n_long, W.long_cap, segs, d_out_off, (uint64_t)out_cap,
-                       reinterpret_cast<uint32_t *>(d_histos));
+                       reinterpret_cast<uint32_t *>(d_histos), W.d_errors);
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[4], st));
@@ -706,6 +787,14 @@ extern "C" int m4g_batch_run_device_codes(m4g_batch *b, const uint8_t *d_src, co
   }
   b->ran = true;
   b->last_stream = st;
+  b->last.d_src = d_src;
+  b->last.src_total = chunk_off[nchunks];
+  b->last.njobs = njobs;
+  b->last.d_out = d_out;
+  b->last.d_out_off = d_out_off;
+  b->last.out_cap = out_cap;
+  b->last.d_histos = d_histos;
+  b->last.d_codes = d_codes;
   return M4G_OK;
 }
 
@@ -717,14 +806,44 @@ int status_from_error_word(uint32_t err) {
 }
 } // namespace
 
-extern "C" int m4g_batch_status(m4g_batch *b) {
-  if (!b) return fail(M4G_ERR_BAD_PARAM, "plan is NULL");
+namespace {
+// Waits for the plan's most recent run and returns its kernel-side outcome.  A compact plan whose record slots
+// overflowed switches to the worst-case layout here (for good) and runs the batch again, on the same stream into
+// the same output buffers: its chain entries, job descriptors and arguments are all still in place.
+int batch_settle(m4g_batch *b) {
   if (!b->ran) return M4G_OK;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->last_stream));
   uint32_t err = 0;
   HIP_TRY(hipMemcpy(&err, b->W.d_errors, 4, hipMemcpyDeviceToHost));
+  if ((err & 2u) && b->W.w.compact()) {
+    spec_use_worst(b->W.w);
+    b->reruns++;
+    if (std::getenv("M4G_TRACE"))
+      std::fprintf(stderr, "[m4g] record slots overflowed: the plan now parses %zu jobs at a time in worst-case slots; running the batch again\n",
+                   b->W.w.group_jobs);
+    const m4g_batch::LastRun &r = b->last;
+    if (int rc = run_batch_pipeline(b->p, b->W, (uint32_t)b->max_chunk_bytes, r.d_src, r.src_total, r.njobs, r.d_out,
+                                    r.d_out_off, r.out_cap, r.d_histos, r.d_codes, b->last_stream, b->timing ? b->ev : nullptr))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    HIP_TRY(hipMemcpy(&err, b->W.d_errors, 4, hipMemcpyDeviceToHost));
+  }
   return status_from_error_word(err);
+}
+} // namespace
+
+extern "C" int m4g_batch_status(m4g_batch *b) {
+  if (!b) return fail(M4G_ERR_BAD_PARAM, "plan is NULL");
+  return batch_settle(b);
+}
+
+extern "C" int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap) {
+  if (!b || !out) return 0;
+  const uint64_t v[5] = {b->bytes, b->W.w.L.slot, b->W.w.slot_worst, b->W.w.group_jobs, b->reruns};
+  const int n = std::min(cap, 5);
+  for (int k = 0; k < n; k++) out[k] = v[k];
+  return n;
 }
 
 // ===========================================================================
@@ -921,7 +1040,7 @@ extern "C" int64_t m4g_batch_encode(m4g_batch *b, const uint8_t *d_src, size_t n
     return fail(M4G_ERR_BAD_PARAM, "NULL argument");
   if (b->last_off.size() != nchunks + 1)
     return fail(M4G_ERR_BAD_PARAM, "m4g_batch_encode: run the plan on these chunks first (m4g_batch_run_device_codes)");
-  HIP_TRY(hipSetDevice(b->device));
+  if (int rc = batch_settle(b)) return rc;
   std::vector<uint64_t> lens(nchunks);
   for (size_t c = 0; c < nchunks; c++) lens[c] = b->last_off[c + 1] - b->last_off[c];
   return brotli_encode_jobs(b->enc, b->ev[0], b->ev[1], d_src, b->W.d_jobs, lens, d_out, d_out_off, d_histos, d_codes,
@@ -979,12 +1098,13 @@ int64_t brotli_encode_uploaded(BlockUpload &U, const m4g_match *matches, size_t 
     HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, U.st, U.d_src,
-                     reinterpret_cast<const uint32_t *>(U.d_m), U.d_jobs, U.d_off, (uint64_t)U.nmatches, D.histos, D.codes);
+                     reinterpret_cast<const uint32_t *>(U.d_m), U.d_jobs, U.d_off, (uint64_t)U.nmatches, D.histos, D.codes,
+                     static_cast<const uint32_t *>(nullptr));
   HIP_TRY(hipGetLastError());
   const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
   if (run_cap) {
     hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, U.st, U.d_src, U.d_jobs, D.runs, D.nruns,
-                       run_cap, segs, U.d_off, (uint64_t)U.nmatches, D.histos);
+                       run_cap, segs, U.d_off, (uint64_t)U.nmatches, D.histos, static_cast<const uint32_t *>(nullptr));
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(U.st)); // (`nruns` and `runs` are stack / pageable)
@@ -1209,7 +1329,7 @@ extern "C" int64_t m4g_batch_flate_encode(m4g_batch *b, const uint8_t *d_src, si
   if (!b || !d_out_off || (nchunks && (!d_src || !d_out))) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
   if (b->last_off.size() != nchunks + 1)
     return fail(M4G_ERR_BAD_PARAM, "m4g_batch_flate_encode: run the plan on these chunks first (m4g_batch_run_device)");
-  HIP_TRY(hipSetDevice(b->device));
+  if (int rc = batch_settle(b)) return rc;
   std::vector<uint64_t> lens(nchunks);
   for (size_t c = 0; c < nchunks; c++) lens[c] = b->last_off[c + 1] - b->last_off[c];
   return flate_encode_jobs(b->flate, b->ev[0], b->ev[1], d_src, b->W.d_jobs, lens, d_out, d_out_off, flags, false,
@@ -1549,7 +1669,7 @@ int64_t batch_one_device_pipelined(const m4g_params *params, const Params &p, co
   PIPE_TRY(hipStreamCreateWithFlags(&P.st_in, hipStreamNonBlocking));
   PIPE_TRY(hipStreamCreateWithFlags(&P.st_run, hipStreamNonBlocking));
   PIPE_TRY(hipStreamCreateWithFlags(&P.st_out, hipStreamNonBlocking));
-  int rc = m4g_batch_create(params, device, slice, max_bytes, &P.plan);
+  int rc = batch_create(params, device, slice, max_bytes, false, &P.plan);
   if (rc) {
     cleanup();
     return rc;
@@ -1684,7 +1804,7 @@ extern "C" int64_t m4g_find_matches_batch(const m4g_params *params, const uint8_
     if (P.chunks.empty()) continue;
     BATCH_TRY(hipSetDevice(P.device));
     BATCH_TRY(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking));
-    rc = m4g_batch_create(params, P.device, P.chunks.size(), max_bytes, &P.plan);
+    rc = batch_create(params, P.device, P.chunks.size(), max_bytes, false, &P.plan);
     if (rc) {
       cleanup();
       return rc;
@@ -2007,7 +2127,7 @@ extern "C" int m4g_hostbatch_create(const m4g_params *params, const int *devices
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.st_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.st_run, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.st_out, hipStreamNonBlocking);
-    if (e == hipSuccess && (rc = m4g_batch_create(params, L.device, L.slice, max_chunk_bytes, &L.plan))) {
+    if (e == hipSuccess && (rc = batch_create(params, L.device, L.slice, max_chunk_bytes, false, &L.plan))) {
       m4g_hostbatch_destroy(h);
       return rc;
     }
@@ -2977,11 +3097,13 @@ int writer_encode(m4g_writer *w, const uint8_t *d_src, const Job *d_jobs, const 
   if (w->format == M4G_FORMAT_BROTLI) {
     const size_t njobs = lens.size();
     hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)njobs), dim3(K5_THREADS), 0, st, d_src,
-                       reinterpret_cast<const uint32_t *>(d_out), d_jobs, d_off, (uint64_t)nmatches, w->d_histos, w->d_codes);
+                       reinterpret_cast<const uint32_t *>(d_out), d_jobs, d_off, (uint64_t)nmatches, w->d_histos, w->d_codes,
+                       static_cast<const uint32_t *>(nullptr));
     HIP_TRY(hipGetLastError());
     const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
     hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, st, d_src, d_jobs, w->d_runs, w->d_nruns,
-                       (uint32_t)(w->runs_cap - 1), segs, d_off, (uint64_t)nmatches, w->d_histos);
+                       (uint32_t)(w->runs_cap - 1), segs, d_off, (uint64_t)nmatches, w->d_histos,
+                       static_cast<const uint32_t *>(nullptr));
     HIP_TRY(hipGetLastError());
     r = brotli_encode_jobs(w->eb, w->e0, w->e1, d_src, d_jobs, lens, d_out, d_off,
                            reinterpret_cast<const m4g_histo *>(w->d_histos), reinterpret_cast<const m4g_code *>(w->d_codes),

@@ -425,10 +425,29 @@ void m4g_writer_destroy(m4g_writer *w);
  * the kernels detect cannot come back through their return value: this call
  * synchronises the stream of that run and returns M4G_OK, M4G_ERR_REPEAT_RANGE
  * or M4G_ERR_INTERNAL (records were dropped; d_out / d_out_off of that run must
- * not be used).  Has no counterpart in the reference (FindMatches cannot fail,
+ * not be used).  It is also where a run that overflowed the plan's compact
+ * record slots is repeated (m4g_batch_info).  Has no counterpart in the reference (FindMatches cannot fail,
  * m4.go:63); callers of the device-resident form check it once per batch, the
  * host-memory forms check it themselves. */
 int m4g_batch_status(m4g_batch *b);
+
+/* Device memory of a plan and the layout of its record slots; no counterpart in
+ * the reference.  A plan from m4g_batch_create holds about 8.1 bytes of
+ * workspace per input byte it is sized for (4 for the chain entries, 4 for the
+ * record slots, which also serve the chain build as scratch): the slots take
+ * one Match per 8 positions of a sub-block, which text, logs and random bytes
+ * of 2 to 4 symbols stay below.  An input with more (the
+ * bound is one per MinLength positions) overflows them; m4g_batch_status -- and
+ * m4g_batch_encode / m4g_batch_flate_encode, which settle the run first -- then
+ * switch the plan for good to slots of the full bound, which the same memory
+ * holds for out[3] chunks at a time, and run the batch again on the same stream
+ * into the same buffers before returning.  So the outputs of a run are final
+ * once one of these calls has returned M4G_OK, not before.  M4G_SLOTS=worst in
+ * the environment: plans start in the full layout (about 12.4 bytes per byte).
+ * out[0] = bytes of device memory, out[1] = Match records per sub-block slot,
+ * out[2] = the full bound, out[3] = chunks parsed at a time (0: all), out[4] =
+ * runs repeated so far (0 or 1).  Returns the number of values written. */
+int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap);
 
 /* Per-stage kernel time of the plan's most recent run, measured with HIP
  * events on the stream the kernels ran on.  Synchronises that stream.

@@ -207,7 +207,9 @@ int64_t sim_find_matches_k3(const uint8_t *src, int32_t n, int max_distance, int
   GlobalMem M{src, chain.data()};
   const SpecGeom g = spec_geom(0, (uint32_t)n, sub_block);
   const uint32_t K = (uint32_t)g.nblocks;
-  const uint32_t slot = (uint32_t)(sub_block / min_length + 18);
+  // SIM_SLOT: a smaller slot than the bound, as a compact batch plan has (m4g.hip spec_alloc): the run must stay
+  // inside its buffers and report the overflow (-2)
+  const uint32_t slot = std::getenv("SIM_SLOT") ? (uint32_t)std::atoi(std::getenv("SIM_SLOT")) : (uint32_t)(sub_block / min_length + 18);
   std::vector<Rec> rs((size_t)K * slot), st((size_t)K * slot);
   std::vector<ParseState> E(K), Tout(K);
   std::vector<BlockDesc> desc(K);

@@ -31,7 +31,7 @@ def _run(blob: np.ndarray, off: np.ndarray, kw, codes=True):
     # poisoned, so records the kernel does not write show up
     d_c = torch.full((2 * cap,), -1, dtype=torch.int32, device=dev) if codes else None
     plan.run(d_src, off, d_out, d_off, d_h, d_codes=d_c)
-    torch.cuda.synchronize()
+    plan.status()
     o = d_off.cpu().numpy()
     out = d_out.cpu().numpy().view(np.uint32).reshape(-1, 3)
     h = d_h.cpu().numpy().view(np.uint32).reshape(-1, 1024)

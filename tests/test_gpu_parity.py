@@ -106,7 +106,7 @@ def _run_batch(host, n, nchunks, kw, histos=True):
     d_off = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
     d_h = torch.empty(nchunks * 1024, dtype=torch.int32, device=dev) if histos else None
     plan.run(d_src, off, d_out, d_off, d_h)
-    torch.cuda.synchronize()
+    plan.status()
     o = d_off.cpu().numpy()
     out = d_out.cpu().numpy().view(np.uint32).reshape(-1, 3)
     h = d_h.cpu().numpy().view(np.uint32).reshape(nchunks, 1024) if histos else None

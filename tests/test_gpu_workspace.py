@@ -1,0 +1,130 @@
+"""GPU tests of the batch plan's compact record slots (include/m4g.h, m4g_batch_info).
+
+A plan keeps one Match record per 8 positions of a sub-block; the reference has
+no such limit (FindMatches appends to a Go slice, m4.go:63-66), so an input
+with more matches than that must come out the same -- through the re-run in the
+worst-case layout that m4g_batch_status (or the encoders over the plan) starts.
+Random bytes of 4 symbols under a chain-walking parameter set are such an
+input: about 150 matches per KiB (measured with the oracle), the slots hold
+130 per KiB sub-block."""
+import numpy as np
+import pytest
+
+from brotli_amd import m4
+from oracle_lib import OracleEncoder, OracleM4, brotli_decompress, histograms
+
+pytestmark = pytest.mark.gpu
+
+DENSE = dict(MaxDistance=1 << 20, MinLength=4, HashLen=5, TableBits=17, ChainLength=8)
+
+
+def same(a, b):
+    a = np.asarray(a, dtype=np.uint32).reshape(-1, 3)
+    b = np.asarray(b, dtype=np.uint32).reshape(-1, 3)
+    return a.shape == b.shape and bool((a == b).all())
+
+
+def _buffers(plan_chunks, nmax, total):
+    import torch
+    dev = torch.device("cuda:0")
+    cap = total // 4 + 2 * plan_chunks + 1
+    return (torch.empty(3 * cap, dtype=torch.int32, device=dev), torch.empty(plan_chunks + 1, dtype=torch.int64, device=dev),
+            torch.empty(plan_chunks * 1024, dtype=torch.int32, device=dev), torch.empty(2 * cap, dtype=torch.int32, device=dev))
+
+
+def _run(plan, chunks, bufs, settle=True):
+    import torch
+    host = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+    off = np.cumsum([0] + [len(c) for c in chunks]).astype(np.uint64)
+    d_src = torch.zeros(host.size + 64, dtype=torch.uint8, device="cuda:0")
+    d_src[:host.size].copy_(torch.from_numpy(host.copy()))
+    d_out, d_off, d_h, d_codes = bufs
+    plan.run(d_src, off, d_out, d_off, d_h, d_codes=d_codes)
+    if settle:
+        plan.status()
+    return d_src
+
+
+def _check_against_oracle(chunks, bufs, kw):
+    d_out, d_off, d_h, _ = bufs
+    C = len(chunks)
+    o = d_off.cpu().numpy()
+    out = d_out.cpu().numpy().view(np.uint32).reshape(-1, 3)
+    h = d_h.cpu().numpy().view(np.uint32).reshape(-1, 1024)
+    assert o[0] == 0
+    for c in range(C):
+        ref = OracleM4(**kw).FindMatches(chunks[c])
+        assert same(out[o[c]:o[c + 1]], ref), f"chunk {c}"
+        lit, cmd, dist, _, _ = histograms(np.frombuffer(chunks[c], dtype=np.uint8), ref)
+        assert (h[c, :256] == lit).all() and (h[c, 256:960] == cmd).all() and (h[c, 960:] == dist).all(), f"chunk {c} histograms"
+
+
+def test_dense_input_overflows_the_compact_slots_and_is_rerun():
+    rng = np.random.default_rng(7)
+    C, n = 64, 1 << 16
+    sizes = [n - (997 * c) % 5000 for c in range(C)]  # ragged
+    dense = [rng.integers(0, 4, s, dtype=np.uint8).tobytes() for s in sizes]
+    plan = m4.BatchPlan(C, n, 0, **DENSE)
+    before = plan.info()
+    assert before["slot"] < before["slot_worst"] and before["group_chunks"] == 0 and before["reruns"] == 0
+    bufs = _buffers(C, n, sum(sizes))
+    _run(plan, dense, bufs)
+    after = plan.info()
+    assert after["reruns"] == 1 and after["slot"] == after["slot_worst"]
+    assert 0 < after["group_chunks"] < C, "the worst-case layout holds the batch in several groups"
+    assert after["bytes"] == before["bytes"], "same memory"
+    _check_against_oracle(dense, bufs, DENSE)
+    # the switch is sticky: the next batches (fewer chunks; more symbols, denser still) run once, group after group
+    dense8 = [rng.integers(0, 8, s, dtype=np.uint8).tobytes() for s in sizes[:41]]
+    _run(plan, dense8, bufs)
+    assert plan.info()["reruns"] == 1
+    _check_against_oracle(dense8, bufs, DENSE)
+    # long literal runs (K4 hands them to the side kernel with the chunk's index in the BATCH, not in its group)
+    mixed = [rng.integers(0, 256, 40000, dtype=np.uint8).tobytes() if c % 7 == 3 else dense[c] for c in range(C)]
+    _run(plan, mixed, bufs)
+    _check_against_oracle(mixed, bufs, DENSE)
+
+
+def test_encoder_over_the_plan_settles_an_overflowed_run_itself():
+    rng = np.random.default_rng(8)
+    C, n = 48, 1 << 16
+    chunks = [rng.integers(0, 4, n, dtype=np.uint8).tobytes() for _ in range(C)]
+    plan = m4.BatchPlan(C, n, 0, **DENSE)
+    bufs = _buffers(C, n, C * n)
+    d_src = _run(plan, chunks, bufs, settle=False)  # no m4g_batch_status in between
+    d_out, d_off, d_h, d_codes = bufs
+    stream, _ = plan.encode(d_src, C, d_out, d_off, d_h, d_codes, first=True, last=True)
+    assert plan.info()["reruns"] == 1
+    data = b"".join(chunks)
+    assert brotli_decompress(stream, len(data)) == data
+    enc, ref = OracleEncoder(), b""
+    for c in chunks:
+        ref += enc.Encode(c, OracleM4(**DENSE).FindMatches(c), False)
+    assert stream == ref + enc.Encode(b"", np.zeros((0, 3), np.uint32), True)
+
+
+def test_inputs_below_the_bound_never_rerun():
+    """4-symbol random bytes under M4's default parameters: 90 records per KiB."""
+    rng = np.random.default_rng(9)
+    C, n = 32, 1 << 16
+    chunks = [rng.integers(0, 4, n, dtype=np.uint8).tobytes() for _ in range(C)]
+    plan = m4.BatchPlan(C, n, 0)
+    bufs = _buffers(C, n, C * n)
+    _run(plan, chunks, bufs)
+    assert plan.info()["reruns"] == 0
+    _check_against_oracle(chunks, bufs, {})
+
+
+def test_headline_plan_fits_34_gib():
+    """the 4096 x 1 MiB plan in at most 34 GiB (it was 47)."""
+    plan = m4.BatchPlan(4096, 1 << 20, 0)
+    info = plan.info()
+    assert info["bytes"] <= 34 << 30, info
+    assert info["bytes"] / (4096 << 20) < 8.5
+    del plan
+
+
+def test_small_plans_keep_the_worst_case_layout():
+    """One chunk: the allocation must hold a whole job in the worst-case layout anyway."""
+    info = m4.BatchPlan(1, 1 << 16, 0).info()
+    assert info["slot"] == info["slot_worst"] and info["group_chunks"] == 0
