@@ -216,3 +216,41 @@ def hand_kats():
     k["q267_tail_clip_too_short"] = (dict(), _layout([1, R[0:6], 1, R[2:11], 2, R[0:11]]), [(21, 9, 13)],
                                      "m4.go:267 length < MinLength")
     return k
+
+
+# ---- Bargain1 / 2 / 3: hand-traced known answers (matchfinder/bargain1.go, bargain3.go) --------------------
+# Every expected Match list below was derived ON PAPER from the reference's source (the traces are in the
+# docstrings of tests/test_bargain_oracle.py::test_hand_traced_*), not taken from a run of the restatement.
+def _distinct(n, start, skip=()):
+    """n distinct byte values from `start` upwards, none of them in `skip`."""
+    out = bytearray()
+    v = start
+    while len(out) < n:
+        if v not in skip:
+            out.append(v)
+        v += 1
+    assert v <= 256
+    return bytes(out)
+
+
+def bargain_kat_phrase_at_odd_position(phrase: bytes) -> bytes:
+    """64 bytes, all distinct, except `phrase` at position 8 (even) and again at position 33 (odd)."""
+    body = bytearray(_distinct(64, 100, skip=set(phrase)))
+    body[8:8 + len(phrase)] = phrase
+    body[33:33 + len(phrase)] = phrase
+    assert len(set(body)) == 64 - len(phrase)
+    return bytes(body)
+
+
+def bargain_kat_twelve_byte_candidate():
+    """Two blocks of 64 bytes.  Block 1: Q (12 distinct bytes) at 4, then Q[:11] + x at 24, then y + Q[1:] at 44,
+    everything else distinct: every 5- and 8-byte window of Q occurs again AFTER position 4, so table5 / table8
+    point at the later copies, and only the 12-byte hash of the whole of Q still leads to position 4.
+    Block 2: 16 distinct bytes, Q, 36 distinct bytes."""
+    Q = bytes(range(65, 77))  # 'A'..'L'
+    fill = _distinct(30 + 52, 100)
+    f1, f2 = fill[:30], fill[30:]
+    b1 = f1[0:4] + Q + f1[4:12] + Q[:11] + f1[12:13] + f1[13:21] + f1[21:22] + Q[1:] + f1[22:30]
+    b2 = f2[:16] + Q + f2[16:]
+    assert len(b1) == 64 and len(b2) == 64 and len(set(b1 + b2)) == 12 + 82
+    return b1, b2

@@ -14,6 +14,7 @@ import struct
 import numpy as np
 import pytest
 
+from cases import bargain_kat_phrase_at_odd_position, bargain_kat_twelve_byte_candidate
 from oracle_lib import OracleBargain, OracleEncoder, brotli_decompress, lib, replay
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -218,6 +219,106 @@ def test_hand_cases():
     z.FindMatches(b"0123456789abcdef" * 2)
     m = z.FindMatches(b"0123456789abcdef").tolist()
     assert m == [[0, 16, 16]]
+
+
+def test_hand_traced_skip_and_back_extension():
+    """Bargain1, one block of 64 bytes (cases.bargain_kat_phrase_at_odd_position): 64 distinct bytes except a phrase
+    at position 8 (even) and again at 33 (odd).  byteCost = max(log2(64 / n), 1): 5 for the phrase's bytes (n = 2),
+    6 for the others; baseMatchCost = 4.  All sums below are exact in float32 (small integers).
+
+    (a) phrase "UVWXYZ" (6 bytes), no Skip.  Arrival costs by literals: position 8: 8 x 6 = 48; 14: 48 + 6 x 5 = 78;
+    33: 78 + 19 x 6 = 192, a literal run of 33 (arrivals[32] = {length 33, distance 0, cost 192}).  i = 33: unmatched
+    = 33; i - unmatched = 0 is not > historyLen, so no previous distance and no repeat probe (bargain1.go:123-125);
+    table6[hash6("UVWXYZ")] = {8, "UVWX"}: extendMatch2(src, 33, 8, 0) runs forward over "YZ" and stops at
+    src[14] != src[39], backward src[32] != src[7]: m = {33, 39, 8}; addMatch: 192 + 4 + Len(33) + Len(25) =
+    192 + 4 + 6 + 5 = 207 for the arrivals at 39, 38, 37, 36 (lengths 6..3; the loop stops at Start + 3,
+    bargain1.go:97).  Literals from 33: 197, 202, then 202 + 5 = 207 at 36, which is not < 207, so the match arrival
+    stays (:130) and the literal path ends there; position 39 costs 207 against 192 + 30 = 222.  Positions 34..38 hash
+    six bytes that occur nowhere else.  From 39 on 25 literals.  Backward walk (:187-203): literal run 25 (attached
+    to an empty Match), match {6, 25}, literal run 33: [[33, 6, 25], [25, 0, 0]].
+
+    (b) the same with Skip: at i = 33 the search is skipped (:159, 33 is odd); at i = 34 the six bytes "VWXYZ" +
+    src[39] differ from "VWXYZ" + src[14], the only other place with these first bytes: no candidate.  Nothing
+    else repeats: [[64, 0, 0]].
+
+    (c) phrase "TUVWXYZ" (7 bytes) with Skip: position 15: 48 + 35 = 83; 33: 83 + 18 x 6 = 191; 34: 196.  i = 33 is
+    skipped.  i = 34 (even): unmatched = 34, table6[hash6("UVWXYZ")] = {9, "UVWX"}: forward over "YZ" to 40,
+    BACKWARD src[33] == src[8] ('T'), src[32] != src[7]: m = {33, 40, 8}, delta = 1, so the match is added twice
+    (:173-178): first from its extended start with unmatched - delta = 33 literals before it: 191 + 4 + Len(33) +
+    Len(25) = 206 for the arrivals at 40..36; then from i itself, {34, 40, 9} with 34 literals: 196 + 4 + 6 + 5 =
+    211, which finds 206 <= 211 at its first arrival and stops (the early exit, :99-100).  Literals: 35: 201; 36:
+    206 is not < 206.  Position 40: 206 against 191 + 35 = 226: [[33, 7, 25], [24, 0, 0]] -- the same as without
+    Skip, where i = 33 finds {33, 40, 8} directly at the same 206.  A restatement that only added the second form
+    would return [[34, 6, 25], ...]; one without the early exit would let 211 overwrite 206 with the same effect."""
+    six, seven = bargain_kat_phrase_at_odd_position(b"UVWXYZ"), bargain_kat_phrase_at_odd_position(b"TUVWXYZ")
+    assert OracleBargain(1, 1 << 20, False).FindMatches(six).tolist() == [[33, 6, 25], [25, 0, 0]]
+    assert OracleBargain(1, 1 << 20, True).FindMatches(six).tolist() == [[64, 0, 0]]
+    assert OracleBargain(1, 1 << 20, True).FindMatches(seven).tolist() == [[33, 7, 25], [24, 0, 0]]
+    assert OracleBargain(1, 1 << 20, False).FindMatches(seven).tolist() == [[33, 7, 25], [24, 0, 0]]
+    # Bargain2 / Bargain3 hash 5 bytes as well: "VWXYZ" at the even position 34 leads to position 9 and the match is
+    # extended back over 'U' (the same two-form addMatch): with Skip they still find the 6-byte phrase
+    for variant in (2, 3):
+        assert OracleBargain(variant, 1 << 20, True).FindMatches(six).tolist() == [[33, 6, 25], [25, 0, 0]]
+    for data, skip in ((six, False), (six, True), (seven, True)):
+        for variant in (1, 2, 3):
+            want = OracleBargain(variant, 1 << 20, skip).FindMatches(data).tolist()
+            assert py_bargain_stream(data, 64, variant, 1 << 20, skip)[0].tolist() == want
+
+
+def test_hand_traced_twelve_byte_hash_is_the_only_way_to_the_best_match():
+    """Bargain3 against Bargain2, two blocks of 64 bytes (cases.bargain_kat_twelve_byte_candidate).  Block 1 holds
+    Q (12 distinct bytes) at 4, Q[:11] + x at 24, y + Q[1:] at 44; block 2 (positions 64..127 of the history) is 16
+    distinct bytes, Q at 80, 36 distinct bytes.  Every byte of block 2 occurs once in it: byteCost = log2(64) = 6.
+    Tables after block 1: table5 / table8 entries of Q's windows point at the LATEST copy (24.. for windows that
+    start at Q[0], 45.. for those that start at Q[1] or later); table12[hash12(Q)] = 4, the only place with all 12.
+
+    Block 2, Bargain3 (bargain3.go:153-254).  Literals: position p costs 6 (p - 64); arrivals[15] (position 80) =
+    {length 16, distance 0, cost 96}.  i = 80: unmatched 16, i - unmatched = 64 is not > historyLen: no repeat probe.
+      candidate5 = {24}: forward Q[4..10], src[35] = x != src[91] = Q[11]: m = {80, 91, 24};
+                   96 + 4 + Len(16) + Len(56) = 96 + 4 + 5 + 6 = 111 for the arrivals at 91..83;
+      candidate8 = {24}: the same match, 111 <= 111 at its first arrival: early exit;
+      candidate12 = {4}: forward to src[16] != src[92]: m = {80, 92, 4}; 96 + 4 + 5 + Len(76) = 96 + 4 + 5 + 7 =
+                   112 for the arrival at 92; at 91 it finds 111 <= 112 and stops.
+      nextOverlapSearch = max(81, 91 - 6, 92 - 6) = 86.
+    i = 81 (unmatched 17, cost 102): candidate5 = candidate8 = {45}: {81, 92, 45}: 102 + 4 + Len(17) + Len(36) =
+      102 + 4 + 5 + 6 = 117, stops at 112 <= 117.  i = 82: {82, 92, 46} extends back to {81, 92, 45}: 117 again, and
+      108 + 4 + 5 + 6 = 123 from 82 itself.  Literals 102, 108, then 108 + 6 = 114 is not < 111 at position 83.
+    i = 83, 84, 85: the arrival is a match (unmatched = 0), i < nextOverlapSearch = 86 and the next arrival is a
+      match too: the gate of :191 (bargain1.go:165) is closed, nothing is searched (the table entries are still written).
+    i = 86, 87: {86, 92, 50} / {87, 92, 51} extend back to {81, 92, 45} with delta 5 / 6: added with
+      max(0 - delta, 0) = 0 literals: 102 + 4 + Len(0) + Len(36) = 102 + 4 + 0 + 6 = 112: a TIE with the arrival at 92,
+      `a.cost <= cost` keeps the first comer (the 12-byte match); from 86 / 87 themselves 111 + 4 + 0 + 6 = 121.
+    Position 92 costs 112 through {length 12, distance 76}; then 36 literals; the repeat probes after it
+      (previous distance 76) compare distinct bytes.  Walk back: [[16, 12, 76], [36, 0, 0]].
+
+    Bargain2 (no table12; the same gate with End - 6): i = 80 gives only the 111 arrivals up to 91; i = 81 sets the
+    arrival at 92 to {11, 36, 117}; i = 86 lowers it to 112 ({81, 92, 45} with 0 literals, as above: 117 > 112).
+    Position 91 + a literal would be 117, not better.  Walk back from 92: length 11 from 81, and position 81 is a
+    literal arrival of run 17: [[17, 11, 36], [36, 0, 0]] -- one byte less matched than Bargain3 at the same cost."""
+    b1, b2 = bargain_kat_twelve_byte_candidate()
+    z3, z2 = OracleBargain(3, 1 << 20), OracleBargain(2, 1 << 20)
+    z3.FindMatches(b1)
+    z2.FindMatches(b1)
+    assert z3.FindMatches(b2).tolist() == [[16, 12, 76], [36, 0, 0]]
+    assert z2.FindMatches(b2).tolist() == [[17, 11, 36], [36, 0, 0]]
+    for variant, want in ((3, [[16, 12, 76], [36, 0, 0]]), (2, [[17, 11, 36], [36, 0, 0]])):
+        m, off = py_bargain_stream(b1 + b2, 64, variant, 1 << 20, False)
+        assert m[int(off[1]):].tolist() == want
+
+
+def test_hand_traced_repeat_probe_is_suppressed_under_a_match_of_that_distance():
+    """The input of test_hand_cases' repeat-probe case, one step further (bargain1.go:150).  i = 39 found the
+    repeat {39, 48, 11} (9 bytes at the previous distance 28) at cost c(39) + 4 + Len(1) + 0.  i = 40 can only be
+    reached by a literal from 39 (a match's first arrival is Start + 3): unmatched = 2, the match before the run is
+    the first one, previous distance 28 -- and arrivals[i + 3] (position 44, under the repeat match) already has
+    distance 28: the probe is skipped.  It could not have changed anything: it would re-add {40, 48, 12} at
+    c(39) + byteCost + 4 + Len(2), more than the arrivals it meets.  So the Match list is the one of i = 39 alone;
+    the branch is reached (profiles/oracle_coverage.txt: both outcomes of bargain_ref.c's distance test)."""
+    P = b"0123456789abcdefghij"
+    data = P + b"ABCDEFGH" + P[:10] + b"#" + P[11:] + b"KLMNOPQR"
+    for variant in (1, 2, 3):
+        assert OracleBargain(variant, 1 << 20).FindMatches(data).tolist() == [[28, 10, 28], [1, 9, 28], [8, 0, 0]]
+        assert py_bargain_stream(data, 1 << 16, variant, 1 << 20, False)[0].tolist() == [[28, 10, 28], [1, 9, 28], [8, 0, 0]]
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3])

@@ -56,6 +56,22 @@ def test_long_stream_is_segmented(variant, md):
     same(a + a[:4_300_001], variant, md=md)
 
 
+def test_hand_traced_kats_on_the_gpu():
+    """The single-block known answers derived on paper in test_bargain_oracle.py (Skip at an odd position, the
+    two-form addMatch of a back-extended candidate, its early exit), here straight against the GPU path."""
+    from cases import bargain_kat_phrase_at_odd_position
+    six, seven = bargain_kat_phrase_at_odd_position(b"UVWXYZ"), bargain_kat_phrase_at_odd_position(b"TUVWXYZ")
+    for data, variant, skip, want in ((six, 1, False, [[33, 6, 25], [25, 0, 0]]), (six, 1, True, [[64, 0, 0]]),
+                                      (seven, 1, True, [[33, 7, 25], [24, 0, 0]]), (seven, 1, False, [[33, 7, 25], [24, 0, 0]]),
+                                      (six, 2, True, [[33, 6, 25], [25, 0, 0]]), (six, 3, True, [[33, 6, 25], [25, 0, 0]])):
+        got, off = m4.bargain_find_blocks(data, variant, 1 << 20, skip)
+        assert got.tolist() == want and off.tolist() == [0, len(want)], (variant, skip)
+    P = b"0123456789abcdefghij"
+    data = P + b"ABCDEFGH" + P[:10] + b"#" + P[11:] + b"KLMNOPQR"
+    for variant in (1, 2, 3):
+        assert m4.bargain_find_blocks(data, variant, 1 << 20)[0].tolist() == [[28, 10, 28], [1, 9, 28], [8, 0, 0]]
+
+
 def test_tiny_and_edges():
     for n in (1, 7, 8, 9, 11, 12, 13, 63, 64, 65, 4095, 4096, 4097):
         for variant in (1, 3):
