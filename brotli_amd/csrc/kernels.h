@@ -1139,6 +1139,28 @@ __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
     return;
   }
   T.error &= kStateErrRange;
+  // A block whose speculative parse emitted nothing, entered with nothing pending and no repeat distance (the
+  // state the speculative parse assumed, up to next_emit): the true parse from T does what the speculative one
+  // did -- the case of k3c's fast path (m4_spec.h) without a probe to check -- so its end state is E[k] with T's
+  // literals and distance carried over, and there is nothing to parse again.  Incompressible stretches are made
+  // of such blocks (measured on random bytes: k3b spent more time re-parsing them than k3a had spent parsing).
+  // The block stays "unsynced": k3c takes Tout as the state entering block k + 1.
+  {
+    const ParseState Ek = E[t];
+    if (d.n_spec == 0 && k + 1 < (uint32_t)g.nblocks && !T.have_prev && fast_entry_ok(T, Ek, block_begin(g, (int32_t)k))) {
+      ParseState R = Ek;
+      R.error = (Ek.error & kStateErrRange) | T.error;
+      R.next_emit = T.next_emit;
+      R.have_prev = T.have_prev;
+      R.prev_dist = T.prev_dist;
+      Tout[t] = R;
+      d.n_stitch = 0;
+      d.keep_from = 0;
+      d.out_off = kStitchUnsynced;
+      desc[t] = d;
+      return;
+    }
+  }
   GlobalMem M{src, chain};
   if (stitch_chase(M, (int32_t)J.len, P, g, k, rs + t * L.slot, L.slot, E + t, desc + t, K3_EXT_LIMIT, T, sink, d))
     Tout[t] = T;

@@ -252,6 +252,21 @@ int64_t sim_find_matches_k3(const uint8_t *src, int32_t n, int max_distance, int
       continue;
     }
     T.error &= kStateErrRange;
+    // the kernel's shortcut for a block that emitted nothing (kernels.h, k3b_stitch)
+    if (d.n_spec == 0 && k + 1 < K && !T.have_prev && fast_entry_ok(T, E[k], block_begin(g, (int32_t)k)) &&
+        !std::getenv("SIM_NO_K3B_SHORTCUT")) {
+      ParseState R = E[k];
+      R.error = (E[k].error & kStateErrRange) | T.error;
+      R.next_emit = T.next_emit;
+      R.have_prev = T.have_prev;
+      R.prev_dist = T.prev_dist;
+      Tout[k] = R;
+      d.n_stitch = 0;
+      d.keep_from = 0;
+      d.out_off = kStitchUnsynced;
+      desc[k] = d;
+      continue;
+    }
     if (stitch_chase(M, n, P, g, k, rs.data() + (size_t)k * slot, slot, E.data() + k, desc.data() + k,
                      ext_limit, T, sink, d))
       Tout[k] = T;
