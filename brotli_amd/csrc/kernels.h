@@ -1408,9 +1408,27 @@ __global__ __launch_bounds__(64) void k3c_validate(
       bool fast = fast_entry_ok(T, Ek, bb);
       if (fast && T.have_prev) {
         const int32_t limit = fast_probe_limit(Ek, be); // positions below it are probed with T's distance
+        // four loop positions per lane and step, from two 8-byte reads (positions i .. i + 3 compare the
+        // 4-byte windows at i + 1 .. i + 4: 7 bytes of each stream); two steps in flight.  Lanes at the edges
+        // of the buffer take the scalar form.  An incompressible stretch behind a match is ALL such blocks,
+        // one wave per chunk walks them in order, and this loop is what it does there.
         bool hit = false;
-        for (int32_t i = bb + lane; i < limit; i += 64)
-          if (fast_probe_hits(src, len, i, T.prev_dist)) hit = true;
+        const int32_t pd = (int32_t)T.prev_dist;
+        auto probe4 = [&](int32_t i) -> bool {
+          if (i >= limit) return false;
+          const int32_t p = i + 1, c = p - pd;
+          if (c >= 0 && p + 8 <= len && i + 4 <= limit) {
+            const uint64_t a = ld64(src + c), b = ld64(src + p), x = a ^ b;
+            return (uint32_t)x == 0 || (uint32_t)(x >> 8) == 0 || (uint32_t)(x >> 16) == 0 || (uint32_t)(x >> 24) == 0;
+          }
+          bool h = false;
+          for (int32_t q = i; q < min(i + 4, limit); q++) h |= fast_probe_hits(src, len, q, T.prev_dist);
+          return h;
+        };
+        for (int32_t i = bb + 4 * lane; i < limit; i += 512) {
+          const bool h0 = probe4(i), h1 = probe4(i + 256);
+          hit |= h0 | h1;
+        }
         if (__ballot(hit)) fast = false;
       }
       if (fast) {
