@@ -2225,8 +2225,6 @@ extern "C" int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t
   if (!h || !chunk_off || (!base && nchunks) || (!stream_out && stream_cap)) return fail(M4G_ERR_BAD_PARAM, "NULL argument");
   if (format != M4G_FORMAT_BROTLI && format != M4G_FORMAT_FLATE && format != M4G_FORMAT_GZIP)
     return fail(M4G_ERR_BAD_PARAM, "unknown format");
-  if (h->lanes.size() != 1)
-    return fail(M4G_ERR_BAD_PARAM, "m4g_hostbatch_compress: one device per stream (make the handle with one device)");
   if (nchunks > h->max_chunks) return fail(M4G_ERR_TOO_LARGE, "nchunks above the handle's max_chunks");
   if (format == M4G_FORMAT_BROTLI && h->p.min_length < 2)
     return fail(M4G_ERR_BAD_PARAM, "the brotli encoder needs MinLength >= 2 (no copy length code for 1)");
@@ -2235,64 +2233,99 @@ extern "C" int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t
     if (chunk_off[c + 1] - chunk_off[c] > h->max_chunk_bytes)
       return fail(M4G_ERR_TOO_LARGE, "chunk larger than the handle's max_chunk_bytes");
   }
-  HostLane &L = h->lanes[0];
-  HIP_TRY(hipSetDevice(L.device));
   const bool brotli = format == M4G_FORMAT_BROTLI;
-  const size_t cap = L.share * (h->max_chunk_bytes / (size_t)h->p.min_length + 2);
-  if (brotli && !L.d_codes && hipMalloc(&L.d_codes, cap * sizeof(CodeRec)) != hipSuccess)
-    return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the per-match code records failed");
-  if (!L.d_cjobs) {
-    if (hipMalloc(&L.d_cjobs, L.share * sizeof(Job)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&L.h_cjobs), L.share * sizeof(Job), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreate(&L.ev_enc[0]) != hipSuccess || hipEventCreate(&L.ev_enc[1]) != hipSuccess)
-      return fail(M4G_ERR_NO_MEMORY, "allocating the encoder's job list failed");
-  }
-  const size_t n = nchunks;
-  L.off.assign(n + 1, 0);
-  L.cap_off.assign(n + 1, 0);
-  for (size_t k = 0; k < n; k++) {
-    const uint64_t len = chunk_off[k + 1] - chunk_off[k];
-    L.off[k + 1] = L.off[k] + len;
-    L.cap_off[k + 1] = L.cap_off[k] + len / (size_t)h->p.min_length + 2;
-    Job J{};
-    J.src_off = L.off[k];
-    J.len = (uint32_t)len;
-    L.h_cjobs[k] = J;
-  }
+  // Several devices: device g takes the g-th CONTIGUOUS range of chunks (stream order), all devices find their
+  // matches at the same time, and the one bit writer of the stream passes over the slices of device 0, then those of
+  // device 1, ... -- each slice is encoded on the device that holds its Match lists, at the bit position where the
+  // previous one stopped, so nothing is moved or shifted afterwards.  The encoder chain (host code building + K6,
+  // about a third of the match finding time of a slice) stays serial; the match finding is what the devices share.
+  const size_t ndev = h->lanes.size();
+  const size_t per = (nchunks + ndev - 1) / std::max<size_t>(ndev, 1);
   auto drain = [&]() { // (copies from / to the caller's buffers must not outlive the call)
-    for (hipStream_t st : {L.st_in, L.st_run, L.st_out}) (void)hipStreamSynchronize(st);
-  };
-  // enqueue: job list, then per slice its upload and its kernels
-  if (n) HIP_TRY(hipMemcpyAsync(L.d_cjobs, L.h_cjobs, n * sizeof(Job), hipMemcpyHostToDevice, L.st_in));
-  const size_t nsl = (n + L.slice - 1) / L.slice;
-  for (size_t s = 0; s < nsl; s++) {
-    const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice), nc = k1 - k0;
-    if (L.off[k1] > L.off[k0])
-      HIP_TRY(hipMemcpyAsync(L.d_src + L.off[k0], base + chunk_off[k0], L.off[k1] - L.off[k0], hipMemcpyHostToDevice, L.st_in));
-    HIP_TRY(hipEventRecord(L.ev_in[s], L.st_in));
-    HIP_TRY(hipStreamWaitEvent(L.st_run, L.ev_in[s], 0));
-    const int rc = m4g_batch_run_device_codes(
-        L.plan, L.d_src, L.off.data() + k0, nc, L.d_out + L.cap_off[k0], L.d_out_off + s * (L.slice + 1),
-        L.cap_off[k1] - L.cap_off[k0], brotli ? L.d_histos + k0 : nullptr,
-        brotli ? reinterpret_cast<m4g_code *>(L.d_codes + L.cap_off[k0]) : nullptr, L.st_run);
-    if (rc) {
-      drain();
-      return rc;
+    for (HostLane &M : h->lanes) {
+      (void)hipSetDevice(M.device);
+      for (hipStream_t st : {M.st_in, M.st_run, M.st_out}) (void)hipStreamSynchronize(st);
     }
-    HIP_TRY(hipMemcpyAsync(L.h_err + s, L.plan->W.d_errors, 4, hipMemcpyDeviceToHost, L.st_run));
-    HIP_TRY(hipEventRecord(L.ev_run[s], L.st_run));
+  };
+  struct Range {
+    size_t c0 = 0, n = 0, nsl = 0;
+  };
+  std::vector<Range> ranges(ndev);
+  // enqueue, device by device: job list, then per slice its upload and its kernels (nothing here waits)
+  for (size_t g = 0; g < ndev; g++) {
+    HostLane &L = h->lanes[g];
+    Range &R = ranges[g];
+    R.c0 = std::min(nchunks, g * per);
+    R.n = std::min(nchunks, R.c0 + per) - R.c0;
+    R.nsl = (R.n + L.slice - 1) / L.slice;
+    if (R.n == 0 && g > 0) continue;
+    HIP_TRY(hipSetDevice(L.device));
+    const size_t cap = L.share * (h->max_chunk_bytes / (size_t)h->p.min_length + 2);
+    if (brotli && !L.d_codes && hipMalloc(&L.d_codes, cap * sizeof(CodeRec)) != hipSuccess) {
+      drain();
+      return fail(M4G_ERR_NO_MEMORY, "hipMalloc of the per-match code records failed");
+    }
+    if (!L.d_cjobs) {
+      if (hipMalloc(&L.d_cjobs, L.share * sizeof(Job)) != hipSuccess ||
+          hipHostMalloc(reinterpret_cast<void **>(&L.h_cjobs), L.share * sizeof(Job), hipHostMallocDefault) != hipSuccess ||
+          hipEventCreate(&L.ev_enc[0]) != hipSuccess || hipEventCreate(&L.ev_enc[1]) != hipSuccess) {
+        drain();
+        return fail(M4G_ERR_NO_MEMORY, "allocating the encoder's job list failed");
+      }
+    }
+    const size_t n = R.n;
+    const uint64_t *coff = chunk_off + R.c0;
+    L.off.assign(n + 1, 0);
+    L.cap_off.assign(n + 1, 0);
+    for (size_t k = 0; k < n; k++) {
+      const uint64_t len = coff[k + 1] - coff[k];
+      L.off[k + 1] = L.off[k] + len;
+      L.cap_off[k + 1] = L.cap_off[k] + len / (size_t)h->p.min_length + 2;
+      Job J{};
+      J.src_off = L.off[k];
+      J.len = (uint32_t)len;
+      L.h_cjobs[k] = J;
+    }
+    if (n) HIP_TRY(hipMemcpyAsync(L.d_cjobs, L.h_cjobs, n * sizeof(Job), hipMemcpyHostToDevice, L.st_in));
+    for (size_t s = 0; s < R.nsl; s++) {
+      const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice), nc = k1 - k0;
+      if (L.off[k1] > L.off[k0])
+        HIP_TRY(hipMemcpyAsync(L.d_src + L.off[k0], base + coff[k0], L.off[k1] - L.off[k0], hipMemcpyHostToDevice, L.st_in));
+      HIP_TRY(hipEventRecord(L.ev_in[s], L.st_in));
+      HIP_TRY(hipStreamWaitEvent(L.st_run, L.ev_in[s], 0));
+      const int rc = m4g_batch_run_device_codes(
+          L.plan, L.d_src, L.off.data() + k0, nc, L.d_out + L.cap_off[k0], L.d_out_off + s * (L.slice + 1),
+          L.cap_off[k1] - L.cap_off[k0], brotli ? L.d_histos + k0 : nullptr,
+          brotli ? reinterpret_cast<m4g_code *>(L.d_codes + L.cap_off[k0]) : nullptr, L.st_run);
+      if (rc) {
+        drain();
+        return rc;
+      }
+      HIP_TRY(hipMemcpyAsync(L.h_err + s, L.plan->W.d_errors, 4, hipMemcpyDeviceToHost, L.st_run));
+      HIP_TRY(hipEventRecord(L.ev_run[s], L.st_run));
+    }
   }
-  // encode slice after slice; the stream continues at bit granularity
+  // the slices of the stream in order: (device, slice) pairs; an empty input is one empty piece on device 0
+  std::vector<std::pair<size_t, size_t>> pieces;
+  for (size_t g = 0; g < ndev; g++)
+    for (size_t s = 0; s < ranges[g].nsl; s++) pieces.emplace_back(g, s);
+  const bool empty = pieces.empty();
+  if (empty) pieces.emplace_back(0, 0);
+  // encode piece after piece; the stream continues at bit granularity
   uint64_t bytes = 0; // whole bytes of the stream so far
   unsigned pend_bits = 0;
   uint8_t pend_byte = 0;
   GzipCarry carry;
-  for (size_t s = 0; s < std::max<size_t>(nsl, 1); s++) {
+  for (size_t q = 0; q < pieces.size(); q++) {
+    const size_t g = pieces[q].first, s = pieces[q].second;
+    HostLane &L = h->lanes[g];
+    const size_t n = ranges[g].n;
     const size_t k0 = s * L.slice, k1 = std::min(n, k0 + L.slice);
-    const bool first = s == 0, last = s + 1 >= nsl;
+    const bool first = q == 0, last = q + 1 >= pieces.size();
     std::vector<uint64_t> lens;
     for (size_t k = k0; k < k1; k++) lens.push_back(L.off[k + 1] - L.off[k]);
-    if (nsl) {
+    HIP_TRY(hipSetDevice(L.device));
+    if (!empty) {
       HIP_TRY(hipEventSynchronize(L.ev_run[s]));
       if (L.h_err[s]) {
         drain();
@@ -2315,10 +2348,9 @@ extern "C" int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t
                             dst, room, L.st_out, nullptr, nullptr, "m4g_hostbatch_compress", pend_bits, &end_bits, &carry);
     if (r < 0) {
       drain();
-      if (r < -(int64_t)M4G_STREAM_NEEDED_BIAS) { // this slice did not fit: a bound for the whole stream
-        uint64_t total = 0;
-        for (size_t k = 0; k < n; k++) total += L.off[k + 1] - L.off[k];
-        return -(int64_t)(total + total / 4 + n * 1024 + 128 + M4G_STREAM_NEEDED_BIAS);
+      if (r < -(int64_t)M4G_STREAM_NEEDED_BIAS) { // this piece did not fit: a bound for the whole stream
+        const uint64_t total = chunk_off[nchunks] - chunk_off[0];
+        return -(int64_t)(total + total / 4 + nchunks * 1024 + 128 + M4G_STREAM_NEEDED_BIAS);
       }
       return r;
     }

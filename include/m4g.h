@@ -260,7 +260,7 @@ int64_t m4g_hostbatch_run(m4g_hostbatch *h, const uint8_t *base, const uint64_t 
 void m4g_hostbatch_destroy(m4g_hostbatch *h);
 
 /* Chunks in host memory -> ONE compressed stream in host memory, on the
- * persistent handle (made with one device): for every chunk c, in order,
+ * persistent handle: for every chunk c, in order,
  * what matchfinder.Writer.writeBlock does (matchfinder.go:81-87) with
  * MatchFinder = AutoReset{&M4{params}} and Encoder = &brotli.Encoder{}
  * (M4G_FORMAT_BROTLI), flate.NewEncoder() (M4G_FORMAT_FLATE) or
@@ -269,7 +269,12 @@ void m4g_hostbatch_destroy(m4g_hostbatch *h);
  * byte-identical to m4g_batch_encode / m4g_batch_flate_encode over the same
  * chunks.  The Match lists never leave the device, so the link carries the
  * input one way and the compressed stream the other (the host-memory batch
- * call is bound by the 12-byte Match records it brings back).  Returns the
+ * call is bound by the 12-byte Match records it brings back).  A handle made
+ * with several devices gives device g the g-th contiguous range of chunks: all
+ * devices find matches at once, and the stream's one bit writer passes over
+ * the slices of device 0, then device 1, ...; each slice is encoded on the
+ * device that holds its Match lists at the bit position where the previous
+ * one stopped.  The bytes do not depend on the device list.  Returns the
  * stream length, -(bound + M4G_STREAM_NEEDED_BIAS) when stream_cap is too small
  * (bound: a capacity that always suffices), or an M4G_ERR_*. */
 int64_t m4g_hostbatch_compress(m4g_hostbatch *h, int format, uint32_t gzip_mtime,

@@ -168,13 +168,18 @@ def test_hostbatch_compress_equals_the_restated_encoders(fmt, kw):
         want += enc.Encode(c, OracleM4(**kw).FindMatches(c), False)
     want += enc.Encode(b"", np.zeros((0, 3), np.uint32), True)
     import os
-    for slice_env in (None, "64"):  # default slices (one here) and 6 slices
+    # default slices (one here) and 6 slices on one device; the device list (0, 0, 0): three lanes with a contiguous
+    # third of the chunks each (107 chunks = one or four slices), the bit writer passing from lane to lane
+    for slice_env, devices in ((None, (0,)), ("64", (0,)), (None, (0, 0, 0)), ("32", (0, 0, 0))):
         if slice_env:
             os.environ["M4G_PIPE_SLICE"] = slice_env
         try:
-            hb = m4.HostBatch(len(sizes), 1 << 17, (0,), **kw)
+            hb = m4.HostBatch(len(sizes), 1 << 17, devices, **kw)
             got = hb.compress(host, off, fmt, mtime=77)
-            assert got == want, slice_env
+            assert got == want, (slice_env, devices)
+            if len(devices) > 1:  # fewer chunks than lanes, and a lane without chunks
+                assert hb.compress(host[:int(off[2])], off[:3], fmt, mtime=77) == \
+                    m4.HostBatch(2, 1 << 17, (0,), **kw).compress(host[:int(off[2])], off[:3], fmt, mtime=77)
             got2 = hb.compress(host[:int(off[5])], off[:6], fmt, mtime=77)  # the handle again, fewer chunks
             assert decode(fmt, got2, int(off[5])) == host[:int(off[5])].tobytes()
             assert decode(fmt, hb.compress(b"", np.zeros(1, np.uint64), fmt, mtime=77), 0) == b""
