@@ -243,7 +243,13 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
     // HashLen 5 on 4 to 10 symbols: 150 - 180 per KiB): their first run overflows, is detected (error bit 1) and
     // repeated in the worst-case layout, which the plan then keeps.  The allocation always holds one job in that
     // layout, and the keys of the split K1 (min_arena_bytes), which are dead before K3 starts.
-    const uint32_t slot_c = std::min<uint32_t>(w.slot_worst, (uint32_t)w.L.sub_block / 8 + 2);
+    // (rounded up to an ODD number of 128-byte lines: measured on 4096 x 1 MiB of text, slots of 258 / 256 / 264 /
+    // 288 records and the worst case: 68.3 / 68.4 / 69.3 / 69.2 / 69.1 GB/s -- unaligned slots cost K4 0.3 ms and K3
+    // 0.6, a power-of-two stride costs K3 0.9)
+    uint32_t slot_c = ((uint32_t)w.L.sub_block / 8 + 2 + 7) / 8;
+    slot_c = std::min<uint32_t>(w.slot_worst, (slot_c | 1u) * 8);
+    if (const char *e = std::getenv("M4G_SLOT_RECS")) // tuning aid
+      slot_c = std::min<uint32_t>(w.slot_worst, (uint32_t)std::max(8, std::atoi(e)));
     size_t recs = std::max(2 * w.blocks * slot_c, 2 * (size_t)w.L.kmax * w.slot_worst);
     recs = std::max(recs, (min_arena_bytes + sizeof(Rec) - 1) / sizeof(Rec));
     if (recs < 2 * nrec) {

@@ -437,7 +437,7 @@ void m4g_writer_destroy(m4g_writer *w);
 int m4g_batch_status(m4g_batch *b);
 
 /* Device memory of a plan and the layout of its record slots; no counterpart in
- * the reference.  A plan from m4g_batch_create holds about 8.1 bytes of
+ * the reference.  A plan from m4g_batch_create holds about 8.3 bytes of
  * workspace per input byte it is sized for (4 for the chain entries, 4 for the
  * record slots, which also serve the chain build as scratch): the slots take
  * one Match per 8 positions of a sub-block, which text, logs and random bytes

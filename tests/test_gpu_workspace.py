@@ -6,7 +6,7 @@ with more matches than that must come out the same -- through the re-run in the
 worst-case layout that m4g_batch_status (or the encoders over the plan) starts.
 Random bytes of 4 symbols under a chain-walking parameter set are such an
 input: about 150 matches per KiB (measured with the oracle), the slots hold
-130 per KiB sub-block."""
+136 per KiB sub-block."""
 import numpy as np
 import pytest
 
