@@ -120,6 +120,10 @@ L.append(f"\nbench.py (HIP events on the launch stream): stage_ms = {b['stage_ms
          f"{b['config']['parity_checked_of']} chunks; cpu_baseline = {b['cpu_baseline']['value']} GB/s on "
          f"{b['cpu_baseline']['cores']} threads ({b['cpu_baseline'].get('value_1thread')} on one); compression ratio "
          f"{b['config']['compression_ratio']}.")
+ws = b["config"].get("workspace")
+if ws:
+    L.append(f"Plan workspace (m4g_batch_info): {ws['bytes'] / 2**30:.2f} GiB = {ws['bytes_per_input_byte']} bytes per input byte, "
+             f"{ws['slot']} Match records per sub-block slot (worst case {ws['slot_worst']}), re-runs after a slot overflow: {ws['reruns']}.")
 L.append(f"Encoder: CPU Encode (restated, one thread) {ce.get('s_per_GiB')} s per GiB; m4g_batch_encode over the 4 GiB "
          f"{ge.get('ms_total')} ms ({ge.get('value')} GB/s: host prefix codes {ge.get('ms_host_prefix_codes')} ms, K6 "
          f"{ge.get('ms_k6_emit_bits')} ms), stream {ge.get('stream_bytes')} bytes, ratio {ge.get('compression_ratio')}.")
