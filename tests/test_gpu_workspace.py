@@ -85,6 +85,61 @@ def test_dense_input_overflows_the_compact_slots_and_is_rerun():
     _check_against_oracle(mixed, bufs, DENSE)
 
 
+@pytest.mark.parametrize("kw,symbols", [(dict(MaxDistance=1 << 20, HashLen=5), 3), (dict(MaxDistance=1 << 20, HashLen=4, MinLength=3), 4),
+                                        (dict(MaxDistance=1 << 16, HashLen=5, ChainLength=64, DistanceBitCost=66), 8)],
+                         ids=["chain0-hash5", "chain0-minlen3", "chain64"])
+def test_overflow_under_other_parameter_sets(kw, symbols):
+    """ChainLength 0 takes the event-driven K3a (k3a_fast): 140-220 records per KiB with HashLen 4 / 5 on 3-4 symbols
+    (tools/analysis/record_density.py's method).  Ragged chunks, some of them tiny or empty."""
+    rng = np.random.default_rng(11 + symbols)
+    n = 1 << 16
+    sizes = [n, 0, 5, n - 1, 4097, n, 1000, n - 333] * 5
+    chunks = [rng.integers(0, symbols, s, dtype=np.uint8).tobytes() for s in sizes]
+    plan = m4.BatchPlan(len(sizes), n, 0, **kw)
+    assert plan.info()["slot"] < plan.info()["slot_worst"]
+    bufs = _buffers(len(sizes), n, sum(sizes) * 4 // (kw.get("MinLength") or 4))
+    _run(plan, chunks, bufs)
+    assert plan.info()["reruns"] == 1
+    _check_against_oracle(chunks, bufs, kw)
+    _run(plan, chunks[::-1], bufs)
+    assert plan.info()["reruns"] == 1
+    _check_against_oracle(chunks[::-1], bufs, kw)
+
+
+def test_overflow_in_a_plan_with_2_kib_sub_blocks():
+    """Plans of a GiB and more use sub-blocks of 2048 positions (264 records per slot); 1024 x 1 MiB of 3-symbol
+    bytes under HashLen 5: 153 records per KiB.  A sample of chunks against the oracle, all of them through the
+    tiling property (Unmatched + Length sums to the chunk length) and the histograms' literal totals."""
+    import torch
+    kw = dict(MaxDistance=1 << 20, HashLen=5)
+    C, n = 1024, 1 << 20
+    rng = np.random.default_rng(21)
+    host = rng.integers(0, 3, C * n, dtype=np.uint8)
+    d_src = torch.from_numpy(host).to("cuda:0")
+    plan = m4.BatchPlan(C, n, 0, **kw)
+    info = plan.info()
+    assert info["slot"] == 264 and info["slot_worst"] == 530
+    off = np.arange(C + 1, dtype=np.uint64) * n
+    d_out = torch.empty(3 * (n // 4 + 2) * C, dtype=torch.int32, device="cuda:0")
+    d_off = torch.empty(C + 1, dtype=torch.int64, device="cuda:0")
+    d_h = torch.empty(C * 1024, dtype=torch.int32, device="cuda:0")
+    plan.run(d_src, off, d_out, d_off, d_h)
+    plan.status()
+    info = plan.info()
+    assert info["reruns"] == 1 and 0 < info["group_chunks"] < C
+    o = d_off.cpu().numpy()
+    out = d_out[:3 * int(o[C])].cpu().numpy().view(np.uint32).reshape(-1, 3)
+    seg = np.repeat(np.arange(C), np.diff(o).astype(np.int64))
+    covered = np.bincount(seg, weights=out[:, 0].astype(np.float64) + out[:, 1], minlength=C)
+    assert (covered == n).all()
+    h = d_h.cpu().numpy().view(np.uint32).reshape(C, 1024)
+    lits = np.bincount(seg, weights=out[:, 0].astype(np.float64), minlength=C)
+    assert (h[:, :256].sum(axis=1) == lits).all()
+    for c in (0, 509, 510, 1019, 1020, 1023):  # around the group boundaries (510 chunks per group)
+        ref = OracleM4(**kw).FindMatches(host[c * n:(c + 1) * n])
+        assert same(out[o[c]:o[c + 1]], ref), c
+
+
 def test_encoder_over_the_plan_settles_an_overflowed_run_itself():
     rng = np.random.default_rng(8)
     C, n = 48, 1 << 16
