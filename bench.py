@@ -318,6 +318,9 @@ def parse_args():
     ap.add_argument("--cpu-1thread-chunks", type=int, default=384)
     ap.add_argument("--encode-sample-chunks", type=int, default=48)
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="time the steps in the library's one-stream form (each kernel alone on the GPU: what a kernel "
+                         "trace should see); by default a large batch runs as two halves on two streams")
     ap.add_argument("--no-gpu-encode", action="store_true",
                     help="skip the m4g_batch_encode leg (Encoder pass 2 on the GPU, SURVEY 8f.2)")
     ap.add_argument("--flate-chunks", type=int, default=256,
@@ -386,7 +389,9 @@ def main():
     off = np.arange(C + 1, dtype=np.uint64) * n
 
     plan = m4.BatchPlan(C, n, local_rank, **kw)
-    plan.set_timing(True)
+    # Stage timing (HIP events between the kernels) belongs to the one-stream form of the pipeline; with it off the
+    # library runs a batch of a GiB and more as two halves on two streams (m4g.hip run_batch_overlapped).
+    plan.set_timing(args.no_overlap)
     # measured match density is ~N/12; size the output for N/6 (checked below)
     out_cap = (n // 6 + 2) * C
     d_out = torch.empty(3 * out_cap, dtype=torch.int32, device=dev)
@@ -421,9 +426,22 @@ def main():
     # per-kernel durations (HIP events recorded by the library on the launch
     # stream): re-run untimed steps so the timed region is not touched
     reps = max(1, min(args.steps, 3))
+    # what the timed (overlapped) steps left behind, to compare with the one-stream form's output below
+    nm_timed = int(d_off[C].item())
+    keep = (d_off.clone(), d_out[:3 * min(nm_timed, out_cap)].clone(), d_h.clone() if d_h is not None else None)
+    plan.set_timing(True)
+    step()  # (the first one-stream run after overlapped ones: untimed)
+    barrier()
+    same_out = bool(torch.equal(keep[0], d_off) and torch.equal(keep[1], d_out[:keep[1].numel()]) and
+                    (d_h is None or torch.equal(keep[2], d_h)))
+    del keep
+    if not same_out:
+        raise SystemExit("the overlapped and the one-stream form of the pipeline disagree")
+    t1 = time.perf_counter()
     for _ in range(reps):
         step()
         stage_ms += np.array(plan.last_timings())
+    one_stream_ms = (time.perf_counter() - t1) / reps * 1e3
     stage_ms /= reps
     plan.status()
 
@@ -560,6 +578,11 @@ def main():
             "workspace": dict(plan.info(), bytes_per_input_byte=round(plan.info()["bytes"] / (C * n), 3)),
         },
         "stage_ms": {names[k]: round(float(stage_ms[k]), 3) for k in range(4)},
+        "overlap": {"timed_steps_overlapped": bool(not args.no_overlap and C * n >= 1 << 30 and C >= 1024),
+                    "one_stream_ms_per_step": round(one_stream_ms, 3),
+                    "outputs_equal_one_stream_form": same_out,
+                    "note": "stage_ms and roofline come from one-stream steps (each kernel alone on the GPU); `value` "
+                            "is the library's default: two halves of the batch on two streams"},
         "roofline": {
             "bound": "hbm",
             "kernel": names[dom],

@@ -1114,7 +1114,14 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
 }
 
 // desc.out_off doubles as the k3b -> k3c status (kStitch*).
-__global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
+// CHAIN = false (ChainLength 0): 6 waves per SIMD (80 registers, 26 spilled) -- the stitch is one lane per block
+// waiting for dependent reads, and more resident waves hide more of them (measured on 4096 x 1 MiB of text, K3 stage:
+// 4 / 5 / 6 / 8 waves 31.30 / 31.15 / 31.06 / 31.54 ms).
+#ifndef M4G_K3B_MINWAVES
+#define M4G_K3B_MINWAVES 6
+#endif
+template <bool CHAIN>
+__global__ __launch_bounds__(K3_THREADS, CHAIN ? 4 : M4G_K3B_MINWAVES) void k3b_stitch(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, const Rec *__restrict__ rs, Rec *__restrict__ st,
     const ParseState *__restrict__ E, ParseState *__restrict__ Tout,
@@ -1162,7 +1169,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3b_stitch(
     }
   }
   GlobalMem M{src, chain};
-  if (stitch_chase(M, (int32_t)J.len, P, g, k, rs + t * L.slot, L.slot, E + t, desc + t, K3_EXT_LIMIT, T, sink, d))
+  if (stitch_chase<CHAIN>(M, (int32_t)J.len, P, g, k, rs + t * L.slot, L.slot, E + t, desc + t, K3_EXT_LIMIT, T, sink, d))
     Tout[t] = T;
   desc[t] = d;
   if (sink.n > L.slot) atomicOr(errors, 2u);

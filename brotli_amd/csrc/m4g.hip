@@ -371,8 +371,12 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
                        w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
   HIP_TRY(hipGetLastError());
   if (w.L.kmax > 1) {
-    hipLaunchKernelGGL(k3b_stitch, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
-                       w.st, w.E, w.Tout, w.desc, d_errors, njobs, w.L, P);
+    if (P.chain_length == 0)
+      hipLaunchKernelGGL(k3b_stitch<false>, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
+                         w.st, w.E, w.Tout, w.desc, d_errors, njobs, w.L, P);
+    else
+      hipLaunchKernelGGL(k3b_stitch<true>, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
+                         w.st, w.E, w.Tout, w.desc, d_errors, njobs, w.L, P);
     HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(k3c_validate, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain, d_jobs,
@@ -479,6 +483,10 @@ struct BatchWork {
   uint32_t long_cap = 0;
   K1Split split;                  // keys alias w.rs when that is large enough (dead until K3), else keys_own
   uint32_t *keys_own = nullptr;
+  // two halves of a large batch on two streams (run_batch_overlapped); plans of m4g_batch_create only
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_scan = nullptr, ev_join = nullptr;
+  const Job *h_jobs = nullptr;    // host image of d_jobs (chain offsets)
 };
 
 // Device buffers of the brotli encoder (K6): owned by a plan (grown on demand) or by one call.
@@ -562,6 +570,9 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->W.d_long_runs);
   (void)hipFree(b->W.split.hdr);
   (void)hipFree(b->W.keys_own);
+  if (b->W.side) (void)hipStreamSynchronize(b->W.side), (void)hipStreamDestroy(b->W.side);
+  for (hipEvent_t e : {b->W.ev_fork, b->W.ev_scan, b->W.ev_join})
+    if (e) (void)hipEventDestroy(e);
   b->enc.release();
   b->flate.release();
   if (b->h_jobs) (void)hipHostFree(b->h_jobs);
@@ -652,6 +663,16 @@ int batch_create(const m4g_params *params, int device, size_t max_chunks, size_t
       return fail(M4G_ERR_HIP, "hipEventCreate failed");
     }
   }
+  b->W.h_jobs = b->h_jobs;
+  if (compact && nbytes >= ((size_t)1 << 30)) { // large plans of the C-ABI: the side stream of run_batch_overlapped
+    if (hipStreamCreateWithFlags(&b->W.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&b->W.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->W.ev_scan, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->W.ev_join, hipEventDisableTiming) != hipSuccess) {
+      m4g_batch_destroy(b);
+      return fail(M4G_ERR_HIP, "creating the plan's side stream failed");
+    }
+  }
   *out = b;
   return M4G_OK;
 }
@@ -688,12 +709,109 @@ int fill_batch_jobs(Job *jobs, const uint64_t *chunk_off, size_t nchunks, size_t
   return M4G_OK;
 }
 
+// The same pipeline for a large batch as TWO halves on two streams: half A on the caller's stream, half B on the
+// plan's side stream.  K1 is bound by instruction issue and K3a by memory round trips, and every launch ends in a
+// tail in which the chip drains: with the halves side by side B's chain build runs next to A's parse and the tails
+// are filled (4 GiB of text: 60.7 ms against 61.7 on one stream).  Both halves start together: holding B back until
+// A's chain build is done (so that B's K1 meets A's K3) gave 62.2 ms, a lower or higher priority for the side stream
+// 62.5 / 62.4 -- the two kernels do not share a CU (K3a fills the registers, k1c the LDS), so what is gained is the
+// tails, not a mix of an issue-bound and a latency-bound kernel.
+// What has to be kept apart: the record slots double as the key scratch of the split K1.  Half A owns the first
+// 2 * jm * kmax * slot records of the allocation (its RS, then its ST), half B the rest; A's keys start at the
+// front (as always), B's keys END at the end of the allocation, so that neither half's keys touch the other half's
+// records (checked below from the jobs' chain offsets; the caller falls back to one stream when it does not fit).
+// B's compaction continues A's offsets (k4_scan_counts' carry), so it waits for A's; the long literal runs are
+// counted after both halves' histograms exist.  Returns 1 when the batch does not qualify.
+int run_batch_overlapped(const Params &p, const BatchWork &W, uint32_t max_len, const uint8_t *d_src,
+                         uint64_t src_total, int njobs, m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
+                         m4g_histo *d_histos, m4g_code *d_codes, hipStream_t st) {
+  static const bool off = std::getenv("M4G_NO_OVERLAP") != nullptr;
+  const SpecWork &w = W.w;
+  if (off || !W.side || !W.h_jobs || !w.arena || w.group_jobs || njobs < 1024 || src_total < ((uint64_t)1 << 30) ||
+      W.split.keys != reinterpret_cast<uint32_t *>(w.rs))
+    return 1;
+  const int jm = njobs / 2, nb = njobs - jm;
+  const uint64_t words_total = (uint64_t)w.arena_recs * (sizeof(Rec) / 4);
+  const uint64_t recs_a = 2ull * (uint64_t)jm * w.L.kmax * w.L.slot, recs_b = 2ull * (uint64_t)nb * w.L.kmax * w.L.slot;
+  if (recs_a + recs_b > w.arena_recs) return 1;
+  const Job &last = W.h_jobs[njobs - 1];
+  const uint64_t chain_end = last.chain_off + (((uint64_t)last.len + 15) & ~15ull); // words
+  const uint64_t chain_mid = W.h_jobs[jm].chain_off;
+  const uint64_t margin = 1024; // words k1c may read past a bin
+  const uint64_t a_words = recs_a * (sizeof(Rec) / 4);
+  if (chain_mid + margin > a_words) return 1;                       // A's keys inside A's records
+  if (words_total < chain_end + margin) return 1;
+  const uint64_t b_shift = words_total - margin - chain_end;        // B's keys: keys + b_shift + chain_off
+  if (b_shift + chain_mid < a_words) return 1;                      // ... and clear of A's records
+  SpecWork va = w, vb = w;
+  va.st = w.rs + (uint64_t)jm * w.L.kmax * w.L.slot;
+  vb.rs = w.rs + recs_a;
+  vb.st = vb.rs + (uint64_t)nb * w.L.kmax * w.L.slot;
+  vb.E = w.E + (uint64_t)jm * w.L.kmax;
+  vb.Tout = w.Tout + (uint64_t)jm * w.L.kmax;
+  vb.desc = w.desc + (uint64_t)jm * w.L.kmax;
+  K1Split sb = W.split;
+  sb.keys = W.split.keys + b_shift;
+  sb.hdr = W.split.hdr + (uint64_t)jm * W.split.kt_max * KP_BINS;
+  hipStream_t s2 = W.side;
+  uint32_t *n_long = W.d_errors + 8;
+  LongRun *runs = d_histos ? W.d_long_runs : nullptr;
+
+  HIP_TRY(hipMemsetAsync(W.d_errors, 0, 64, st));
+  HIP_TRY(hipEventRecord(W.ev_fork, st)); // inputs, job descriptors and the cleared error word are in place
+  HIP_TRY(hipStreamWaitEvent(s2, W.ev_fork, 0));
+  int rc;
+  // half A: K1, K3, K4
+  if ((rc = launch_k1(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, jm, st, nullptr, nullptr, &W.split))) return rc;
+  if ((rc = launch_parse(p, d_src, src_total, W.d_chain, W.d_jobs, jm, va, W.d_counts, W.d_errors, st))) return rc;
+  if ((rc = launch_compact(va, W.d_jobs, W.d_counts, jm, d_out_off, d_out, out_cap, st, runs, n_long, W.long_cap, 0))) return rc;
+  HIP_TRY(hipEventRecord(W.ev_scan, st));
+  // half B: K1, K3, then K4 behind A's
+  if ((rc = launch_k1(p, d_src, src_total, max_len, W.d_chain, W.d_jobs + jm, nullptr, nb, s2, nullptr, nullptr, &sb))) return rc;
+  if ((rc = launch_parse(p, d_src, src_total, W.d_chain, W.d_jobs + jm, nb, vb, W.d_counts + jm, W.d_errors, s2))) return rc;
+  HIP_TRY(hipStreamWaitEvent(s2, W.ev_scan, 0));
+  if ((rc = launch_compact(vb, W.d_jobs + jm, W.d_counts + jm, nb, d_out_off + jm, d_out, out_cap, s2, runs, n_long, W.long_cap,
+                           (uint32_t)jm)))
+    return rc;
+  if (d_histos) {
+    auto k5 = [&](int j0, int nj, hipStream_t s) {
+      uint32_t *h = reinterpret_cast<uint32_t *>(d_histos) + (size_t)j0 * 1024;
+      if (d_codes)
+        hipLaunchKernelGGL(k5_histograms<true>, dim3((unsigned)nj), dim3(K5_THREADS), 0, s, d_src,
+                           reinterpret_cast<const uint32_t *>(d_out), W.d_jobs + j0, d_out_off + j0, (uint64_t)out_cap, h,
+                           reinterpret_cast<CodeRec *>(d_codes), W.d_errors);
+      else
+        hipLaunchKernelGGL(k5_histograms<false>, dim3((unsigned)nj), dim3(K5_THREADS), 0, s, d_src,
+                           reinterpret_cast<const uint32_t *>(d_out), W.d_jobs + j0, d_out_off + j0, (uint64_t)out_cap, h,
+                           static_cast<CodeRec *>(nullptr), W.d_errors);
+    };
+    k5(0, jm, st);
+    HIP_TRY(hipGetLastError());
+    k5(jm, nb, s2);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(W.ev_join, s2));
+  HIP_TRY(hipStreamWaitEvent(st, W.ev_join, 0));
+  if (d_histos) {
+    const uint32_t segs = (uint32_t)(((size_t)max_len + K5B_SEG - 1) / K5B_SEG);
+    hipLaunchKernelGGL(k5b_long_literals, dim3(2048), dim3(K5B_THREADS), 0, st, d_src, W.d_jobs,
+                       W.d_long_runs, n_long, W.long_cap, segs, d_out_off, (uint64_t)out_cap,
+                       reinterpret_cast<uint32_t *>(d_histos), W.d_errors);
+    HIP_TRY(hipGetLastError());
+  }
+  return M4G_OK;
+}
+
 // K1 -> K3 -> K4 -> K5 for the njobs jobs already in W.d_jobs.  Everything is
 // enqueued on st; nothing here allocates or synchronises.  ev: five events
 // (stage boundaries) or null.
 int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, const uint8_t *d_src,
                        uint64_t src_total, int njobs, m4g_match *d_out, uint64_t *d_out_off, size_t out_cap,
                        m4g_histo *d_histos, m4g_code *d_codes, hipStream_t st, hipEvent_t *ev) {
+  if (!ev) { // (the stage events belong to the one-stream form)
+    const int r2 = run_batch_overlapped(p, W, max_len, d_src, src_total, njobs, d_out, d_out_off, out_cap, d_histos, d_codes, st);
+    if (r2 != 1) return r2;
+  }
   HIP_TRY(hipMemsetAsync(W.d_errors, 0, 64, st));
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
   int rc = launch_k1(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, st, nullptr, nullptr, &W.split);

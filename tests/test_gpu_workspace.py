@@ -183,3 +183,39 @@ def test_small_plans_keep_the_worst_case_layout():
     """One chunk: the allocation must hold a whole job in the worst-case layout anyway."""
     info = m4.BatchPlan(1, 1 << 16, 0).info()
     assert info["slot"] == info["slot_worst"] and info["group_chunks"] == 0
+
+
+def test_two_halves_on_two_streams_equal_the_one_stream_form():
+    """A batch of a GiB and more runs as two halves on two streams (m4g.hip run_batch_overlapped) unless the plan's
+    stage timing is on.  Ragged chunks (so that the halves' chain offsets are not round numbers), Match lists,
+    offsets and histograms of both forms equal, and equal to the oracle around the cut and at the ends."""
+    import torch
+    from brotli_amd import synth
+    C, n = 1100, 1 << 20
+    sizes = np.array([n - (7919 * c) % 30011 for c in range(C)], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    host = np.empty(C * n, dtype=np.uint8)
+    synth.fill(host, n, 500, "text", 16)
+    host = host[:int(off[C])]
+    d_src = torch.from_numpy(host).to("cuda:0")
+    plan = m4.BatchPlan(C, n, 0, MaxDistance=1 << 20, DistanceBitCost=66)
+    cap = (n // 6 + 2) * C
+    outs = []
+    for timing in (False, True, False):
+        d_out = torch.zeros(3 * cap, dtype=torch.int32, device="cuda:0")
+        d_off = torch.zeros(C + 1, dtype=torch.int64, device="cuda:0")
+        d_h = torch.zeros(C * 1024, dtype=torch.int32, device="cuda:0")
+        plan.set_timing(timing)
+        plan.run(d_src, off, d_out, d_off, d_h)
+        plan.status()
+        outs.append((d_off, d_out, d_h))
+    assert plan.info()["reruns"] == 0
+    for k in (1, 2):
+        assert torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]) and torch.equal(outs[0][2], outs[k][2])
+    o = outs[0][0].cpu().numpy()
+    assert int(o[C]) <= cap
+    out = outs[0][1][:3 * int(o[C])].cpu().numpy().view(np.uint32).reshape(-1, 3)
+    kw = dict(MaxDistance=1 << 20, DistanceBitCost=66)
+    for c in (0, 1, 548, 549, 550, 551, C - 1):
+        ref = OracleM4(**kw).FindMatches(host[int(off[c]):int(off[c + 1])])
+        assert same(out[o[c]:o[c + 1]], ref), c

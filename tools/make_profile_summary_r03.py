@@ -20,6 +20,14 @@ def short(n):
 
 
 def per_kernel(sub, counter):
+    j = os.path.join(run, sub + ".json")  # made on the GPU box by tools/pmc_extract.py (same query as below)
+    if os.path.exists(j):
+        acc = {}
+        for n, (tot, cnt) in json.load(open(j)).get(counter, {}).items():
+            a = acc.setdefault(short(n), [0.0, 0])
+            a[0] += tot
+            a[1] += cnt
+        return {k: v[0] / v[1] for k, v in acc.items()}
     out = {}
     for f in glob.glob(os.path.join(run, sub, "**", "*.db"), recursive=True):
         db = sqlite3.connect(f)
@@ -44,6 +52,10 @@ _, ms1k = stats_of("trace1k")
 shutil.copy(stats_file, P(f"{tag}_kernel_stats.csv"))
 try:
     shutil.copy(stats_of("trace_legs")[0], P(f"{tag}_kernel_stats_legs.csv"))
+except Exception:
+    pass
+try:  # the default (overlapped) form: half-size launches next to each other, durations not comparable with stage_ms
+    shutil.copy(stats_of("trace_ov")[0], P(f"{tag}_kernel_stats_overlapped.csv"))
 except Exception:
     pass
 b = last_json(os.path.join(run, "bench.json"))
@@ -105,7 +117,8 @@ open(P(f"{tag}_counters.md"), "w").write("\n".join(T) + "\n")
 rows = [r for r in csv.DictReader(open(stats_file)) if "m4g" in r["Name"]]
 L = [f"# Round {tag[1:]} profile summary (1 x MI355X)\n",
      "Made by `tools/profile_run_r03.sh` + `tools/make_profile_summary_r03.py`.",
-     "Trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0`",
+     "Trace: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-overlap --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0`",
+     "(`--no-overlap`: the one-stream form of the pipeline, every kernel alone on the GPU -- the durations `stage_ms` and `roofline` of every bench line are made of; the default run overlaps two halves of the batch on two streams, DESIGN.md section 5).",
      f"(4096 x 1 MiB synthetic text chunks, params G; the run also makes the gpu_encode leg, hence k6 and k5_histograms<true>; the kernels of the flate and writer legs, 256 chunks: `profiles/{tag}_kernel_stats_legs.csv`).",
      f"Raw: `profiles/{tag}_kernel_stats.csv`; bench line of the plain `python bench.py` run: `profiles/{tag}_bench.json`;",
      f"counter table: `profiles/{tag}_counters.md`; HBM-side bytes per input byte: `profiles/traffic.json`.\n",
@@ -114,7 +127,8 @@ for r in rows:
     L.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
 e2e, ge, ce = b.get("end_to_end", {}), b.get("gpu_encode", {}), b.get("cpu_encode", {})
 L.append(f"\nbench.py (HIP events on the launch stream): stage_ms = {b['stage_ms']}, value = {b['value']} GB/s "
-         f"({b['ms_per_step']} ms per 4 GiB step), roofline.achieved = {b['roofline']['achieved']} GB/s of 8000 "
+         f"({b['ms_per_step']} ms per 4 GiB step; one stream: {b.get('overlap', {}).get('one_stream_ms_per_step')} ms; outputs of the two forms equal: "
+         f"{b.get('overlap', {}).get('outputs_equal_one_stream_form')}), roofline.achieved = {b['roofline']['achieved']} GB/s of 8000 "
          f"({b['roofline']['frac']}; kernel {b['roofline']['kernel']}), roofline.traffic = {b['roofline']['traffic']} GB, "
          f"whole path {b['roofline'].get('whole_path_frac')}; parity checked on {b['config']['parity_checked_chunks']} of "
          f"{b['config']['parity_checked_of']} chunks; cpu_baseline = {b['cpu_baseline']['value']} GB/s on "

@@ -8,7 +8,7 @@ out=gpurun_out/${1:-run}
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 step() { name=$1; shift; echo "== $name" >&2; "$@" || { echo "step $name failed (rc $?)" >&2; exit 1; }; }
-B1K="python3 bench.py --chunks 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --verify-chunks 0 --flate-chunks 0 --writer-mib 0 --bargain-chunks 0"
+B1K="python3 bench.py --no-overlap --chunks 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --verify-chunks 0 --flate-chunks 0 --writer-mib 0 --bargain-chunks 0"
 pmc() { name=$1; shift; args=$1; shift
   step "pmc_$name" bash -c "timeout -s KILL 150 rocprofv3 --pmc $* -d $out/pmc_$name -- $B1K $args > $out/pmc_$name.log 2>&1"; }
 step tests   bash -c "timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $out/gpu_tests.log 2>&1"
@@ -16,7 +16,8 @@ step smoke   bash -c "timeout -k 10 120 python __graft_entry__.py smoke > $out/s
 step bench   bash -c "timeout -k 10 500 python bench.py > $out/bench.json 2> $out/bench.err"
 step log     bash -c "timeout -k 10 200 python bench.py --chunks 1024 --kind log --no-end-to-end --writer-mib 0 > $out/bench_log.json 2>> $out/bench.err"
 step D       bash -c "timeout -k 10 300 python bench.py --chunks 1024 --params D --no-end-to-end --flate-chunks 0 --writer-mib 0 --bargain-chunks 0 > $out/bench_D.json 2>> $out/bench.err"
-step trace   bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0 --bargain-chunks 0 > $out/trace.log 2>&1"
+step trace   bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-overlap --no-cpu-baseline --no-end-to-end --verify-chunks 2 --flate-chunks 0 --writer-mib 0 --bargain-chunks 0 > $out/trace.log 2>&1"
+step traceov bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_ov -- python3 bench.py --no-cpu-baseline --no-end-to-end --no-gpu-encode --verify-chunks 2 --flate-chunks 0 --writer-mib 0 --bargain-chunks 0 > $out/trace_ov.log 2>&1"
 step tracel  bash -c "timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_legs -- python3 bench.py --chunks 256 --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --verify-chunks 0 > $out/trace_legs.log 2>&1"
 step trace1k bash -c "timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1k -- $B1K > $out/trace1k.log 2>&1"
 pmc fetch "" FETCH_SIZE
@@ -27,6 +28,7 @@ pmc fetch_D "--params D --no-gpu-encode" FETCH_SIZE
 pmc write_D "--params D --no-gpu-encode" WRITE_SIZE
 pmc fetch_log "--kind log --no-gpu-encode" FETCH_SIZE
 pmc write_log "--kind log --no-gpu-encode" WRITE_SIZE
+step pmcx    bash -c "python3 tools/pmc_extract.py $out > $out/pmc_extract.log 2>&1"
 step kinds   bash -c "timeout -k 10 300 python tools/kind_probe.py > $out/kind_probe.log 2>&1"
 step stream  bash -c "timeout -k 10 200 python tools/stream_probe.py 256 > $out/stream_probe.log 2>&1"
 step hostb   bash -c "timeout -k 10 200 python tools/hostbatch_probe.py 2048 > $out/hostbatch_probe.log 2>&1"
