@@ -698,6 +698,9 @@ __device__ __forceinline__ uint64_t k3_wave_of_block(uint32_t b, uint32_t nblock
 // 40000 bytes repeated at random (256 x 1 MiB): 4096 -> 18.7 / 19.4 / 26.4 GB/s,
 // 2048 -> 18.4 / 27.2 / 32.2, 1024 -> 15.9 / 29.3 / 33.0 (k3c, one wave per chunk,
 // then redoes too many blocks of the first input); text is indifferent.
+// Round 3, with k3a_fast (tools/ext_ab.sh): 1024 -> 16.9 / 31.0 / 36.0, 2048 -> 24.9 / 28.8 / 36.3, 3072 -> 23.8 /
+// 25.0 / 34.0, 4096 -> 25.2 / 20.8 / 30.9, 8192 -> 23.8 / 12.3 / 20.5; at 1024 chunks, where k3c's one wave per chunk
+// is no longer the bound, 2048 gives 45.4 / 48.6 / 52.3.
 #ifndef M4G_K3_EXT_LIMIT
 #define M4G_K3_EXT_LIMIT 2048
 #endif
