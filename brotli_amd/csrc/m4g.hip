@@ -1137,6 +1137,18 @@ struct BlockUpload {
     off[njobs] = block_off[nlists];
     nmatches = block_off[nlists];
     if (nmatches && !matches && !borrowed) return fail(M4G_ERR_BAD_PARAM, "matches is NULL");
+    // A caller's lists must stay inside their blocks: the encoders read src[pos .. pos + Unmatched) for every match
+    // (the reference slices the same way and panics on a list that runs past the block, encoder.go:45-52).
+    for (size_t j = 0; j < njobs; j++)
+      if (off[j + 1] < off[j]) return fail(M4G_ERR_BAD_PARAM, "block_off not ascending");
+    if (matches && !borrowed)
+      for (size_t j = 0; j < njobs; j++) {
+        uint64_t pos = 0;
+        for (uint64_t k = off[j]; k < off[j + 1]; k++) {
+          pos += (uint64_t)matches[k].unmatched + matches[k].length;
+          if (pos > lens[j]) return fail(M4G_ERR_BAD_PARAM, "a Match list runs past the end of its block");
+        }
+      }
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));

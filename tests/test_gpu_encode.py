@@ -117,3 +117,42 @@ def test_writer_drop_in_edge_sizes():
         out = m4.brotli_compress(data, bs, **PARAMS_G)
         assert brotli_decompress(out, len(data)) == data
         assert out == OracleM4(**PARAMS_G).compress(data, bs)[0], (len(data), bs)
+
+
+ERR_BAD_PARAM = -1000002  # M4G_ERR_BAD_PARAM (include/m4g.h)
+
+
+def test_lists_that_run_past_their_block_are_refused():
+    """Encoder.Encode slices src[pos : pos + Unmatched] for every match (encoder.go:45-52) and panics on a list that
+    runs past the block; the C-ABI forms that take a caller's lists refuse them before any kernel reads by them."""
+    import ctypes
+    data = np.frombuffer(synth.text(100000, 3), dtype=np.uint8)
+    bs = 1 << 16
+    matches, off = m4.M4(**PARAMS_G).find_matches_blocks(data, bs)
+    out = np.zeros(data.size + 4096, dtype=np.uint8)
+
+    def brotli(m, o):
+        m = np.ascontiguousarray(m, dtype=np.uint32)
+        o = np.ascontiguousarray(o, dtype=np.uint64)
+        return m4.lib().m4g_brotli_encode_blocks(0, data.ctypes.data, data.size, bs, m.ctypes.data, o.ctypes.data,
+                                                 out.ctypes.data, out.size)
+
+    def flate(m, o):
+        m = np.ascontiguousarray(m, dtype=np.uint32)
+        o = np.ascontiguousarray(o, dtype=np.uint64)
+        return m4.lib().m4g_flate_encode_blocks(0, data.ctypes.data, data.size, bs, m.ctypes.data, o.ctypes.data, 0, 0,
+                                                out.ctypes.data, out.size, None)
+
+    assert brotli(matches, off) > 0
+    bad = matches.copy()
+    bad[5, 0] += 70000                      # literals beyond the block
+    assert brotli(bad, off) == ERR_BAD_PARAM and flate(bad, off) == ERR_BAD_PARAM
+    bad = matches.copy()
+    bad[int(off[1]) - 1, 1] += 1            # the last match of block 0 one byte too long
+    assert brotli(bad, off) == ERR_BAD_PARAM
+    bad = matches.copy()
+    bad[3, 0] = 0xFFFFFFFF                  # sums that wrap 32 bits
+    assert brotli(bad, off) == ERR_BAD_PARAM
+    boff = off.copy()
+    boff[1] = off[2] + 1                    # offsets not ascending
+    assert brotli(matches, boff) == ERR_BAD_PARAM
