@@ -1202,6 +1202,10 @@ int64_t brotli_encode_uploaded(BlockUpload &U, const m4g_match *matches, size_t 
     for (uint64_t k = U.off[j]; k < U.off[j + 1]; k++) {
       if (matches[k].length == 1) // no copy length code for 1 (command.go:128); M4 never returns it with MinLength >= 2
         return fail(M4G_ERR_BAD_PARAM, std::string(what) + ": a match of Length 1");
+      // the Encoder's distance histogram has 64 symbols (encoder.go:37): symbol 16 + 2 (nbits - 1) + prefix < 64 means
+      // Distance + 3 < 2^26 (the reference indexes past its array beyond that and panics)
+      if (matches[k].length != 0 && (((uint64_t)matches[k].distance + 3) >> 26) != 0)
+        return fail(M4G_ERR_BAD_PARAM, std::string(what) + ": a Distance beyond the Encoder's 64 distance symbols");
       if (matches[k].unmatched >= K5_HUGE) runs.push_back(LongRun{(uint32_t)j, pos, matches[k].unmatched, 0});
       pos += matches[k].unmatched + matches[k].length;
     }

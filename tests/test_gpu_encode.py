@@ -153,6 +153,11 @@ def test_lists_that_run_past_their_block_are_refused():
     bad = matches.copy()
     bad[3, 0] = 0xFFFFFFFF                  # sums that wrap 32 bits
     assert brotli(bad, off) == ERR_BAD_PARAM
+    bad = matches.copy()
+    bad[7, 2] = (1 << 26) - 3               # distance symbol 64: past the Encoder's histogram (encoder.go:35, 97)
+    assert brotli(bad, off) == ERR_BAD_PARAM
+    bad[7, 2] = (1 << 26) - 4               # symbol 63 is the last one
+    assert brotli(bad, off) > 0
     boff = off.copy()
     boff[1] = off[2] + 1                    # offsets not ascending
     assert brotli(matches, boff) == ERR_BAD_PARAM
