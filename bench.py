@@ -578,7 +578,7 @@ def main():
             "workspace": dict(plan.info(), bytes_per_input_byte=round(plan.info()["bytes"] / (C * n), 3)),
         },
         "stage_ms": {names[k]: round(float(stage_ms[k]), 3) for k in range(4)},
-        "overlap": {"timed_steps_overlapped": bool(not args.no_overlap and C * n >= 1 << 30 and C >= 1024),
+        "overlap": {"timed_steps_overlapped": bool(not args.no_overlap and C * n >= 1 << 29 and C >= 512),
                     "one_stream_ms_per_step": round(one_stream_ms, 3),
                     "outputs_equal_one_stream_form": same_out,
                     "note": "stage_ms and roofline come from one-stream steps (each kernel alone on the GPU); `value` "

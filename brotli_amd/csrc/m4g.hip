@@ -664,7 +664,7 @@ int batch_create(const m4g_params *params, int device, size_t max_chunks, size_t
     }
   }
   b->W.h_jobs = b->h_jobs;
-  if (compact && nbytes >= ((size_t)1 << 30)) { // large plans of the C-ABI: the side stream of run_batch_overlapped
+  if (compact && nbytes >= ((size_t)1 << 28)) { // large plans of the C-ABI: the side stream of run_batch_overlapped
     if (hipStreamCreateWithFlags(&b->W.side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&b->W.ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->W.ev_scan, hipEventDisableTiming) != hipSuccess ||
@@ -727,7 +727,10 @@ int run_batch_overlapped(const Params &p, const BatchWork &W, uint32_t max_len, 
                          m4g_histo *d_histos, m4g_code *d_codes, hipStream_t st) {
   static const bool off = std::getenv("M4G_NO_OVERLAP") != nullptr;
   const SpecWork &w = W.w;
-  if (off || !W.side || !W.h_jobs || !w.arena || w.group_jobs || njobs < 1024 || src_total < ((uint64_t)1 << 30) ||
+  // (tools/overlap_ab.sh, text in 1 MiB chunks, overlapped against one stream: 256 chunks 5.10 / 5.10 ms, 512: 8.66 /
+  // 8.86, 1024: 15.96 / 16.01, 2048: 30.93 / 31.32, 4096: 60.8 / 61.9)
+  static const int min_jobs = std::getenv("M4G_OVERLAP_MIN_CHUNKS") ? std::atoi(std::getenv("M4G_OVERLAP_MIN_CHUNKS")) : 512;
+  if (off || !W.side || !W.h_jobs || !w.arena || w.group_jobs || njobs < min_jobs || src_total < (uint64_t)min_jobs << 20 ||
       W.split.keys != reinterpret_cast<uint32_t *>(w.rs))
     return 1;
   const int jm = njobs / 2, nb = njobs - jm;
