@@ -569,6 +569,9 @@ struct StagedMem {
   const uint32_t *lch;  // LDS row of this lane: chain[w0 .. w0 + K3_W)
   int32_t w0;
   int32_t give_up_at;   // > 0: a match reaching this position makes the caller drop the parse (k3a)
+  const K2Res *k2;      // K2's results for this job's positions, or null (m4_k2.h)
+  __device__ __forceinline__ bool has_k2() const { return k2 != nullptr; }
+  __device__ __forceinline__ const K2Res *k2_ptr(int32_t p) const { return k2 + p; }
   __device__ __forceinline__ uint8_t ld8(int32_t p) const {
     const uint32_t o = (uint32_t)(p - w0 + K3_BACK);
     if (o < (uint32_t)K3_SRC_BYTES) return (uint8_t)(lsrc[o >> 2] >> (8 * (o & 3)));
@@ -737,6 +740,7 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   M.lsrc = lds_src + lane * K3_SRC_DW;
   M.lch = lds_ch + lane * K3_CH_DW;
   M.give_up_at = len_eff < len ? len_eff : 0;
+  M.k2 = P.k2 ? P.k2 + J.chain_off : nullptr;
   bool aborted = false;
 
   for (int32_t e = 0; e < L.sub_block; e += K3_W) { // uniform trip count
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(K3_THREADS, CHAIN ? 4 : M4G_K3B_MINWAVES) void k3b_
       return;
     }
   }
-  GlobalMem M{src, chain};
+  GlobalMem M{src, chain, CHAIN && P.k2 ? P.k2 + J.chain_off : nullptr};
   if (stitch_chase<CHAIN>(M, (int32_t)J.len, P, g, k, rs + t * L.slot, L.slot, E + t, desc + t, K3_EXT_LIMIT, T, sink, d))
     Tout[t] = T;
   desc[t] = d;
@@ -1478,6 +1482,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
       WaveMem M;
       M.src = src;
       M.chain = chain;
+      M.k2 = P.k2 ? P.k2 + J.chain_off : nullptr;
       k3c_stage(M, c_src, c_ch, len, bb, be, lane);
       // the block's speculative records, which the stitch scans for a common flush, staged the same way
       const Rec *spec = rs + t * L.slot;

@@ -34,12 +34,16 @@
 
 namespace m4g {
 
+struct K2Res;
 struct ParseParams {
   int32_t max_distance;
   int32_t min_length;
   int32_t hash_len;
   int32_t chain_length;
   int32_t distance_bit_cost;
+  // results of kernel K2 for the chain array the parse reads (element j of it speaks about chain[j]), or null:
+  // set by the host for plans that run K2 (m4_k2.h); the kernels hand job J's part to their memory accessor
+  const K2Res *k2 = nullptr;
 };
 
 // emitter.go:5-16; end == 0 <=> the reference's zero-valued absoluteMatch
@@ -89,9 +93,24 @@ M4G_HD uint64_t ld64(const uint8_t *p) {
 // Memory accessor of the parse: every read of the input bytes and of the chain
 // array goes through one of these, so kernels can substitute a staged (LDS)
 // view for the positions a lane is currently walking (kernels.h, StagedMem).
+// Results of kernel K2 (m4_k2.h explains them)
+constexpr int K2_FW = 32;      // bytes compared forward (from the position)
+constexpr int K2_BW = 16;      // bytes compared backward (before the position)
+constexpr int K2_ENTRIES = 4;  // candidates kept per position
+// One kept candidate = one word: bits 0..21 distance, 22..26 forward length - 4 (28: K2_FW bytes agree, the
+// match may go on), 27..31 backward length (16: K2_BW bytes agree, it may go on).  0: no entry.
+constexpr uint32_t kK2DistBits = 22, kK2DistMask = (1u << kK2DistBits) - 1;
+constexpr uint32_t kK2FwdCapped = K2_FW - 4, kK2BwdCapped = K2_BW;
+constexpr uint32_t kK2Fallback = 0xFFFFFFFFu; // in e[0]: more than K2_ENTRIES candidates matter, walk the chain
+constexpr int32_t kK2MaxLen = 1 << kK2DistBits; // chunks shorter than this can use K2
+struct K2Res {
+  uint32_t e[K2_ENTRIES];
+};
+static_assert(sizeof(K2Res) == 16, "one 16-byte word per position");
 struct GlobalMem {
   const uint8_t *src;
   const uint32_t *chain;
+  const K2Res *k2 = nullptr; // per-position results of K2 (m4_k2.h), or none
   M4G_HD uint8_t ld8(int32_t p) const { return src[p]; }
   M4G_HD uint32_t ld32(int32_t p) const { return m4g::ld32(src + p); }
   M4G_HD uint64_t ld64(int32_t p) const { return m4g::ld64(src + p); }
@@ -101,6 +120,8 @@ struct GlobalMem {
   // reads the light filter of parse_range makes: positions the caller guarantees to be "near"
   M4G_HD uint32_t near_chain(int32_t p) const { return chain[p]; }
   M4G_HD uint32_t near32(int32_t p) const { return m4g::ld32(src + p); }
+  M4G_HD bool has_k2() const { return k2 != nullptr; }
+  M4G_HD const K2Res *k2_ptr(int32_t p) const { return k2 + p; }
 };
 
 M4G_HD int32_t bitlen32(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
@@ -286,6 +307,10 @@ M4G_HD int32_t next_pos(const ParseState &S, const ParseParams &P, int32_t i) {
   return (probe > i && probe < S.m0.end) ? probe : S.m0.end;
 }
 
+} // namespace m4g
+#include "m4_k2.h"
+namespace m4g {
+
 // Runs loop iterations of m4.go:112-260 while S.i < stop (stop <= len-7).
 // M reads the input bytes / chain array by buffer position; `len` is the
 // buffer length (forward extension may read up to len, never past it).
@@ -323,6 +348,8 @@ template <bool STOP_AT_FLUSH = false, bool LIGHT = false, bool CHAIN = true, boo
 M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseState &S,
                         int32_t stop, Sink &sink) {
   int32_t i = S.i;
+  bool k2_on = false; // the walks of m4.go:156-181 come from K2 (m4_k2.h)
+  if constexpr (CHAIN) k2_on = P.chain_length > 0 && M.has_k2();
   // 8 source bytes of the repeat probe, kept across iterations: consecutive
   // literal positions probe consecutive addresses (same prev_dist).
   uint64_t pc_bytes = 0;
@@ -336,7 +363,9 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
           break;
         }
         const uint32_t le = M.near_chain(i);
-        if ((le & kChainDelta) - 1u < (uint32_t)P.max_distance && ((le & kChainMaybe) || P.chain_length > 0)) {
+        // (with K2's results the mark of an entry says "some candidate of the walk can be accepted")
+        if ((le & kChainDelta) - 1u < (uint32_t)P.max_distance &&
+            ((le & kChainMaybe) || (P.chain_length > 0 && !(CHAIN && k2_on)))) {
           event = true; // a candidate to look at
           break;
         }
@@ -378,7 +407,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     const uint32_t d = ce & kChainDelta;
     const bool cand_ok = d != 0 && d <= (uint32_t)P.max_distance;
     int32_t cand = i - (int32_t)d;
-    const bool cand_fast = FUSED && cand_ok && (ce & kChainMaybe) && cand >= 8; // i+8 <= len always
+    const bool cand_fast = FUSED && cand_ok && (ce & kChainMaybe) && cand >= 8 && !k2_on; // i+8 <= len always
     const bool cand_fast2 = cand_fast && i + 16 <= len;
 
     uint64_t pl = 0, cf = 0, cb = 0, cf2 = 0;
@@ -387,6 +416,11 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       cf = M.far64(cand_fast ? cand : 0);
       cb = M.far64(cand_fast ? cand - 8 : 0);
       cf2 = M.far64(cand_fast2 ? cand + 8 : 0);
+    }
+    K2Res k2r{};
+    if constexpr (CHAIN) {
+      // (read with the other far words of the iteration; positions without an accepted candidate have no mark)
+      if (k2_on && cand_ok && (ce & kChainMaybe)) __builtin_memcpy(&k2r, M.k2_ptr(i), sizeof(K2Res));
     }
 
     // B. m4.go:128-138 repeat match one byte after the current position
@@ -434,7 +468,17 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     AbsMatch cur{0, 0, 0};
     int64_t cur_score = 0;
     AbsMatch m;
-    if (ce & kChainMaybe) {
+    bool walk = true;
+    if constexpr (CHAIN) {
+      if (k2_on) {
+        walk = (ce & kChainMaybe) && k2r.e[0] == kK2Fallback;
+        if ((ce & kChainMaybe) && !walk) {
+          M4G_STAT(30);
+          k2_select(M, len, P, S, i, k2r, cur, cur_score);
+        }
+      }
+    }
+    if (walk && (ce & kChainMaybe)) {
       M4G_STAT(9);
       const bool hit = cand_fast ? match_regs(M, len, i, cand, S.next_emit, cf, cf2, cand_fast2, cb, m)
                                  : match_at(M, len, i, cand, S.next_emit, m);
@@ -454,8 +498,8 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     }
     // m4.go:166-181.  The chain entry of a candidate and the bytes around it are
     // read together (one far round trip per hop instead of two dependent ones).
-    uint32_t next_entry = CHAIN && P.chain_length > 0 ? M.chain_at(cand) : 0u;
-    for (int32_t j = 0; CHAIN && j < P.chain_length; j++) {
+    uint32_t next_entry = CHAIN && walk && P.chain_length > 0 ? M.chain_at(cand) : 0u;
+    for (int32_t j = 0; CHAIN && walk && j < P.chain_length; j++) {
       uint32_t dd = next_entry & kChainDelta;
       if (dd == 0) break;
       M4G_STAT(24);
