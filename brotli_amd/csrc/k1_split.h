@@ -62,7 +62,8 @@ static_assert(k1c_lds_bytes(15) <= 160 * 1024, "LDS of one CU");
 __global__ __launch_bounds__(KP_THREADS, 8) void k1p_partition(
     const uint8_t *__restrict__ src_base, uint64_t src_total, uint32_t *__restrict__ keys_base,
     uint32_t *__restrict__ hdr_base, uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, int njobs,
-    uint32_t kt_max, uint32_t groups_per_job, int hash_len, int table_bits, int bin_bits, int check_bits) {
+    uint32_t kt_max, uint32_t groups_per_job, int hash_len, int table_bits, int bin_bits, int check_bits,
+    int fold /* 0: every inserted position gets a key (k1d_depth, k2_eval.h, counts them) */) {
   __shared__ uint32_t cnt[16 * KP_CSTRIDE]; // [wave][bin]: keys of the wave in the bin, then their first slot
   __shared__ uint32_t tot[KP_BINS];
   __shared__ uint32_t stage[KP_TILE];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(KP_THREADS, 8) void k1p_partition(
         const uint32_t ph = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)hv, 0x138, 0xf, 0xf, false); // wave_shr:1
         const uint32_t pck = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ck, 0x138, 0xf, 0xf, false);
         const uint32_t nh = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)hv, 0x130, 0xf, 0xf, false); // wave_shl:1
-        if (hv == ph) { // (position sb + rel >= 1 here; a predecessor at position 0 counts as "empty", m4.go:152)
+        if (fold && hv == ph) { // (position sb + rel >= 1 here; a predecessor at position 0 counts as "empty", m4.go:152)
           chain_base[J.chain_off + sb + rel] = sb + rel > 1 ? (1u | (pck == ck ? kChainMaybe : 0u)) : 0u;
           if (hv == nh) bin[j] = KP_BINS;
           else key[j] |= KP_KEY_SET_ONLY;

@@ -505,6 +505,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_chain_build(
 } // namespace m4g
 #include "k1_xchg.h"
 #include "k1_split.h"
+#include "k2_eval.h"
 namespace m4g {
 
 // ---------------------------------------------------------------------------

@@ -116,6 +116,9 @@ int k1_prepare(uint32_t *d_word = nullptr) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1c_scatter),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)k1c_lds_bytes(kMaxPartBits)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1d_depth),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)k1c_lds_bytes(kMaxPartBits)));
   return M4G_OK;
 }
 
@@ -300,7 +303,9 @@ bool k1_split_usable(const Params &p) {
 // of one stream (null otherwise).
 int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_t max_len,
               uint32_t *d_chain, const Job *d_jobs, uint32_t *d_table_io, int njobs, hipStream_t st,
-              const StreamInfo *d_si, uint32_t *d_table_out = nullptr, const K1Split *split = nullptr) {
+              const StreamInfo *d_si, uint32_t *d_table_out = nullptr, const K1Split *split = nullptr,
+              bool fold = true /* false: a key for every position (K2 counts them) */, bool *split_ran = nullptr) {
+  if (split_ran) *split_ran = false;
   const int pb = part_bits_of(p);
   const int nparts = 1 << (p.table_bits - pb);
   const int groups = (njobs + 7) / 8;
@@ -318,8 +323,10 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
     const uint32_t gpj = (split->kt_max + KP_TPW - 1) / KP_TPW;
     const int bin_bits = (p.table_bits - pb) + 4;
     hipLaunchKernelGGL(k1p_partition, dim3((unsigned)njobs * gpj), dim3(KP_THREADS), 0, st, d_src, src_total,
-                       split->keys, split->hdr, d_chain, d_jobs, njobs, split->kt_max, gpj, p.hash_len, p.table_bits, bin_bits, cb);
+                       split->keys, split->hdr, d_chain, d_jobs, njobs, split->kt_max, gpj, p.hash_len, p.table_bits, bin_bits, cb,
+                       fold ? 1 : 0);
     HIP_TRY(hipGetLastError());
+    if (split_ran) *split_ran = true;
     static const bool image = std::getenv("M4G_K1C_SCATTER") == nullptr;
     if (image)
       hipLaunchKernelGGL(k1c_consume, g1, dim3(KP_THREADS), k1c_lds_bytes(pb), st, split->keys, split->hdr, d_chain,
@@ -352,8 +359,9 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
 // in w.rs / w.st as described by w.desc.
 int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, const uint32_t *d_chain,
                  const Job *d_jobs, int njobs, const SpecWork &w, uint32_t *d_counts, uint32_t *d_errors,
-                 hipStream_t st) {
-  const ParseParams P = parse_params(p);
+                 hipStream_t st, const K2Res *k2 = nullptr /* K2's results for d_chain's positions (launch_k2) */) {
+  ParseParams P = parse_params(p);
+  P.k2 = k2;
   const uint64_t lanes = (uint64_t)njobs * w.L.kmax;
   const unsigned g3 = (unsigned)((lanes + K3_THREADS - 1) / K3_THREADS);
   // tuning aid: unused dynamic LDS per workgroup = fewer waves per CU = fewer chunks in flight per XCD
@@ -363,7 +371,7 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
   if (P.chain_length == 0 && w.L.kmax % K3_THREADS == 0 && !k3a_slow)
     hipLaunchKernelGGL(k3a_fast, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
                        w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
-  else if (P.chain_length == 0)
+  else if (P.chain_length == 0 || k2) // (with K2's results only marked entries are events, as without chains)
     hipLaunchKernelGGL(k3a_spec<true>, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
                        w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
   else
@@ -381,6 +389,46 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
   }
   hipLaunchKernelGGL(k3c_validate, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain, d_jobs,
                      w.rs, w.st, w.E, w.Tout, w.desc, d_counts, d_errors, njobs, w.L, P);
+  HIP_TRY(hipGetLastError());
+  return M4G_OK;
+}
+
+// Device buffers of K2 (k2_eval.h) for a batch plan.
+struct K2Work {
+  bool on = false;
+  uint32_t *sorted = nullptr; // the positions of every job grouped by table index (indexed like the chain array)
+  uint32_t *base = nullptr;   // njobs << table_bits: bucket sizes, then bucket bases
+  K2Res *res = nullptr;       // one per chain entry; until k2_place has run its first quarter holds the depths
+  size_t bytes = 0;
+};
+// K2 serves fresh-state jobs built by the split K1, whose positions and distances fit the packed entries.
+bool k2_usable(const Params &p, size_t max_chunk_bytes) {
+  static const bool off = std::getenv("M4G_NO_K2") != nullptr;
+  return !off && p.chain_length > 0 && p.chain_length <= K2_MAX_CHAIN && p.distance_bit_cost >= 0 &&
+         p.min_length >= 1 && max_chunk_bytes < (size_t)kK2MaxLen;
+}
+// K2 for the jobs in d_jobs, whose un-folded keys the split K1 has just left in split.keys / split.hdr.
+int launch_k2(const Params &p, const K2Work &k, const K1Split &split, const uint8_t *d_src, uint64_t src_total,
+              uint32_t max_len, uint32_t *d_chain, const Job *d_jobs, int njobs, hipStream_t st) {
+  const int pb = part_bits_of(p);
+  const int nparts = 1 << (p.table_bits - pb);
+  const int groups = (njobs + 7) / 8;
+  int posbits = 1;
+  while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
+  const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits)); // as launch_k1
+  uint32_t *depth = reinterpret_cast<uint32_t *>(k.res);
+  hipLaunchKernelGGL(k1d_depth, dim3((unsigned)(groups * 8 * nparts)), dim3(KP_THREADS), k1s_lds_bytes(pb), st, split.keys,
+                     split.hdr, depth, 1u, k.base, d_jobs, njobs, split.kt_max, p.table_bits, pb, cb);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k2_scan_sizes, dim3((unsigned)njobs), dim3(1024), 0, st, k.base, njobs, p.table_bits);
+  HIP_TRY(hipGetLastError());
+  const uint32_t wpj_p = (max_len + K2P_THREADS * K2P_PER - 1) / (K2P_THREADS * K2P_PER);
+  hipLaunchKernelGGL(k2_place, dim3((unsigned)groups * 8 * wpj_p), dim3(K2P_THREADS), 0, st, d_src, depth, 1u, k.base,
+                     k.sorted, d_jobs, njobs, wpj_p, p.hash_len, p.table_bits);
+  HIP_TRY(hipGetLastError());
+  const uint32_t wpj_e = (max_len + K2E_THREADS - 1) / K2E_THREADS;
+  hipLaunchKernelGGL(k2_eval, dim3((unsigned)groups * 8 * wpj_e), dim3(K2E_THREADS), 0, st, d_src, src_total, k.sorted,
+                     d_chain, k.res, d_jobs, njobs, wpj_e, parse_params(p));
   HIP_TRY(hipGetLastError());
   return M4G_OK;
 }
@@ -483,6 +531,7 @@ struct BatchWork {
   uint32_t long_cap = 0;
   K1Split split;                  // keys alias w.rs when that is large enough (dead until K3), else keys_own
   uint32_t *keys_own = nullptr;
+  K2Work k2;                      // ChainLength > 0: the chain walks as a kernel of their own (k2_eval.h)
   // two halves of a large batch on two streams (run_batch_overlapped); plans of m4g_batch_create only
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_scan = nullptr, ev_join = nullptr;
@@ -570,6 +619,9 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->W.d_long_runs);
   (void)hipFree(b->W.split.hdr);
   (void)hipFree(b->W.keys_own);
+  (void)hipFree(b->W.k2.sorted);
+  (void)hipFree(b->W.k2.base);
+  (void)hipFree(b->W.k2.res);
   if (b->W.side) (void)hipStreamSynchronize(b->W.side), (void)hipStreamDestroy(b->W.side);
   for (hipEvent_t e : {b->W.ev_fork, b->W.ev_scan, b->W.ev_join})
     if (e) (void)hipEventDestroy(e);
@@ -657,6 +709,22 @@ int batch_create(const m4g_params *params, int device, size_t max_chunks, size_t
     }
     b->bytes += hdr_bytes;
   }
+  if (split && b->W.split.keys && k2_usable(p, max_chunk_bytes)) {
+    K2Work &k = b->W.k2;
+    const size_t entries = chain_bytes / 4 + 1024;
+    const size_t base_bytes = (max_chunks << p.table_bits) * 4;
+    if (hipMalloc(&k.sorted, entries * 4) != hipSuccess || hipMalloc(&k.base, base_bytes) != hipSuccess ||
+        hipMalloc(&k.res, entries * sizeof(K2Res)) != hipSuccess) {
+      // (not an error: the plan runs without K2, walking the chains inside the parse)
+      (void)hipGetLastError();
+      (void)hipFree(k.sorted), (void)hipFree(k.base), (void)hipFree(k.res);
+      k = K2Work{};
+    } else {
+      k.on = true;
+      k.bytes = entries * (4 + sizeof(K2Res)) + base_bytes;
+      b->bytes += k.bytes;
+    }
+  }
   for (auto &ev : b->ev) {
     if (hipEventCreate(&ev) != hipSuccess) {
       m4g_batch_destroy(b);
@@ -730,7 +798,7 @@ int run_batch_overlapped(const Params &p, const BatchWork &W, uint32_t max_len, 
   // (tools/overlap_ab.sh, text in 1 MiB chunks, overlapped against one stream: 256 chunks 5.10 / 5.10 ms, 512: 8.66 /
   // 8.86, 1024: 15.96 / 16.01, 2048: 30.93 / 31.32, 4096: 60.8 / 61.9)
   static const int min_jobs = std::getenv("M4G_OVERLAP_MIN_CHUNKS") ? std::atoi(std::getenv("M4G_OVERLAP_MIN_CHUNKS")) : 512;
-  if (off || !W.side || !W.h_jobs || !w.arena || w.group_jobs || njobs < min_jobs || src_total < (uint64_t)min_jobs << 20 ||
+  if (off || W.k2.on || !W.side || !W.h_jobs || !w.arena || w.group_jobs || njobs < min_jobs || src_total < (uint64_t)min_jobs << 20 ||
       W.split.keys != reinterpret_cast<uint32_t *>(w.rs))
     return 1;
   const int jm = njobs / 2, nb = njobs - jm;
@@ -817,8 +885,15 @@ int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, co
   }
   HIP_TRY(hipMemsetAsync(W.d_errors, 0, 64, st));
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
-  int rc = launch_k1(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, st, nullptr, nullptr, &W.split);
+  bool split_ran = false;
+  int rc = launch_k1(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, st, nullptr, nullptr, &W.split,
+                     !W.k2.on, &split_ran);
   if (rc) return rc;
+  const K2Res *k2 = nullptr;
+  if (W.k2.on && split_ran) { // (stage K1 of the timing events includes K2)
+    if ((rc = launch_k2(p, W.k2, W.split, d_src, src_total, max_len, W.d_chain, W.d_jobs, njobs, st))) return rc;
+    k2 = W.k2.res;
+  }
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   uint32_t *n_long = W.d_errors + 8; // zeroed with d_errors above
   // K3 + K4, for all jobs at once -- or, for a compact plan after its switch to the worst-case layout, group after
@@ -827,7 +902,7 @@ int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, co
   const int group = W.w.group_jobs ? (int)std::min<size_t>(W.w.group_jobs, (size_t)njobs) : njobs;
   for (int j0 = 0; j0 < njobs; j0 += group) {
     const int nj = std::min(group, njobs - j0);
-    if ((rc = launch_parse(p, d_src, src_total, W.d_chain, W.d_jobs + j0, nj, W.w, W.d_counts + j0, W.d_errors, st)))
+    if ((rc = launch_parse(p, d_src, src_total, W.d_chain, W.d_jobs + j0, nj, W.w, W.d_counts + j0, W.d_errors, st, k2)))
       return rc;
     if (ev && j0 + nj >= njobs) HIP_TRY(hipEventRecord(ev[2], st));
     if ((rc = launch_compact(W.w, W.d_jobs + j0, W.d_counts + j0, nj, d_out_off + j0, d_out, out_cap, st,
@@ -967,10 +1042,33 @@ extern "C" int m4g_batch_status(m4g_batch *b) {
 
 extern "C" int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap) {
   if (!b || !out) return 0;
-  const uint64_t v[5] = {b->bytes, b->W.w.L.slot, b->W.w.slot_worst, b->W.w.group_jobs, b->reruns};
-  const int n = std::min(cap, 5);
+  const uint64_t v[7] = {b->bytes, b->W.w.L.slot, b->W.w.slot_worst, b->W.w.group_jobs, b->reruns,
+                         b->W.k2.on ? 1u : 0u, b->W.k2.bytes};
+  const int n = std::min(cap, 7);
   for (int k = 0; k < n; k++) out[k] = v[k];
   return n;
+}
+
+// Test hooks for K2 (k2_eval.h).  _set_k2: a plan that holds K2's buffers runs with (1) or without (0) it from
+// the next run on; returns whether the plan holds them.  _dump_k2: after a run (synchronises its stream), the
+// chain entries (mark bit included) and K2's results of chunk c of that run, n = the chunk's length each.
+extern "C" int m4g_debug_batch_set_k2(m4g_batch *b, int on) {
+  if (!b || !b->W.k2.res) return 0;
+  b->W.k2.on = on != 0;
+  return 1;
+}
+extern "C" int m4g_debug_batch_dump_k2(m4g_batch *b, size_t c, uint32_t *chain_out, uint32_t *res_out, size_t n) {
+  if (!b || !b->ran || c >= (size_t)b->last.njobs) return fail(M4G_ERR_BAD_PARAM, "no run, or no such chunk");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  const Job &J = b->h_jobs[c];
+  if (n > J.len) return fail(M4G_ERR_BAD_PARAM, "n above the chunk's length");
+  if (chain_out) HIP_TRY(hipMemcpy(chain_out, b->W.d_chain + J.chain_off, n * 4, hipMemcpyDeviceToHost));
+  if (res_out) {
+    if (!b->W.k2.res) return fail(M4G_ERR_BAD_PARAM, "the plan has no K2 buffers");
+    HIP_TRY(hipMemcpy(res_out, b->W.k2.res + J.chain_off, n * sizeof(K2Res), hipMemcpyDeviceToHost));
+  }
+  return M4G_OK;
 }
 
 // ===========================================================================

@@ -451,8 +451,19 @@ int m4g_batch_status(m4g_batch *b);
  * the environment: plans start in the full layout (about 12.4 bytes per byte).
  * out[0] = bytes of device memory, out[1] = Match records per sub-block slot,
  * out[2] = the full bound, out[3] = chunks parsed at a time (0: all), out[4] =
- * runs repeated so far (0 or 1).  Returns the number of values written. */
+ * runs repeated so far (0 or 1).  Returns the number of values written.
+ * out[5] = 1 when the plan evaluates the chain walks in a kernel of their own
+ * (K2; ChainLength > 0, chunks below 4 MiB, DistanceBitCost >= 0), out[6] =
+ * the device memory that takes (included in out[0]). */
 int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap);
+/* Test hooks for K2, the data-parallel form of the chain walks of m4.go:156-181
+ * (no counterpart in the reference: results are the same with and without).
+ * _set_k2: a plan that holds K2's buffers runs with (on = 1) or without it from
+ * the next run on; returns 1 when the plan holds them, else 0.  _dump_k2: after
+ * a run, chunk c's chain entries and per-position K2 results (4 words each),
+ * n <= the chunk's length of each, to host memory (either may be NULL). */
+int m4g_debug_batch_set_k2(m4g_batch *b, int on);
+int m4g_debug_batch_dump_k2(m4g_batch *b, size_t c, uint32_t *chain_out, uint32_t *res_out, size_t n);
 
 /* Per-stage kernel time of the plan's most recent run, measured with HIP
  * events on the stream the kernels ran on.  Synchronises that stream.

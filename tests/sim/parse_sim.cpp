@@ -412,4 +412,73 @@ int64_t sim_find_matches_k3(const uint8_t *src, int32_t n, int max_distance, int
   return (err & 1u) ? INT64_MIN : (int64_t)result.size();
 }
 #endif
+
+// K2 on the host, by walking the chains (the kernels k1d_depth / k2_place / k2_eval get the same candidates from
+// the bucket-sorted position list): per position 4 words of K2Res and, in mark[i], whether the position's chain
+// entry carries the mark afterwards.  The reference for tests/test_gpu_k2.py; m4_k2.h explains the contents.
+void sim_k2_reference(const uint8_t *src, int32_t n, int max_distance, int min_length, int hash_len, int table_bits,
+                      int chain_length, int distance_bit_cost, uint32_t *res_out, uint8_t *mark_out) {
+  std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
+  build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
+  auto window = [&](int p, uint32_t *w) {
+    uint8_t b[K2_BW + K2_FW];
+    for (int k = 0; k < K2_BW + K2_FW; k++) {
+      const int q = p - K2_BW + k;
+      b[k] = (q >= 0 && q < n) ? src[q] : 0xA5; // what lies outside the buffer must not matter
+    }
+    std::memcpy(w, b, sizeof(b));
+  };
+  for (int i = 0; i < n; i++) {
+    K2Res r{};
+    int cnt = 0;
+    bool fb = false;
+    if (i < n - 7) {
+      uint32_t d = chain[i] & kChainDelta;
+      int cand = i;
+      uint32_t wi[12];
+      window(i, wi);
+      for (int j = 0; j <= chain_length && !fb; j++) { // the table entry, then ChainLength hops (m4.go:159,166)
+        if (d == 0 || d >= (uint32_t)cand) break;       // none, or position 0 and below (m4.go:152,172)
+        cand -= (int)d;
+        if (i - cand > max_distance) break;
+        uint32_t wc[12], code;
+        window(cand, wc);
+        const int af = n - i < K2_FW ? n - i : K2_FW, ab = cand < K2_BW ? cand : K2_BW;
+        if (k2_pair(wi, wc, af, ab, code) && !k2_add(r.e, cnt, (uint32_t)(i - cand) | code, min_length, distance_bit_cost))
+          fb = true;
+        d = chain[cand] & kChainDelta;
+      }
+    }
+    if (fb) {
+      r = K2Res{};
+      r.e[0] = kK2Fallback;
+    }
+    std::memcpy(res_out + 4 * (size_t)i, r.e, 16);
+    mark_out[i] = fb || cnt > 0;
+  }
+}
+
+// One fresh-state FindMatches whose parse takes its chain walks from K2's results (computed as above).
+int64_t sim_find_matches_k2(const uint8_t *src, int32_t n, int max_distance, int min_length, int hash_len,
+                            int table_bits, int chain_length, int distance_bit_cost, uint32_t seed_prev,
+                            uint32_t *out, int64_t out_cap) {
+  ParseParams P{max_distance, min_length, hash_len, chain_length, distance_bit_cost};
+  std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
+  build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
+  std::vector<K2Res> res((size_t)n + 1);
+  std::vector<uint8_t> mark((size_t)n + 1);
+  sim_k2_reference(src, n, max_distance, min_length, hash_len, table_bits, chain_length, distance_bit_cost,
+                   reinterpret_cast<uint32_t *>(res.data()), mark.data());
+  for (int i = 0; i < n; i++) chain[i] = (chain[i] & kChainDelta) | (mark[i] ? kChainMaybe : 0u);
+  VecSink sink;
+  ParseState S;
+  state_init(S, 0, seed_prev);
+  GlobalMem M{src, chain.data(), res.data()};
+  parse_range<false, true>(M, n, P, S, n - 7, sink);
+  parse_finish(n, P, S, sink);
+  if ((int64_t)sink.v.size() > out_cap) return -(int64_t)sink.v.size();
+  for (auto &r : sink.v) r.lit_start &= ~kRecFlushBit;
+  if (!sink.v.empty()) std::memcpy(out, sink.v.data(), sink.v.size() * sizeof(Rec));
+  return (S.error & m4g::kStateErrRange) ? INT64_MIN : (int64_t)sink.v.size();
+}
 }

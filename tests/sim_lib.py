@@ -62,3 +62,27 @@ def sim_k3(data, sub_block, ext_limit=4096, legacy_limit=False, seed=0, **kw):
                               1 if legacy_limit else 0, out.ctypes.data, len(out), stats.ctypes.data)
     assert r >= 0, r
     return out[:r, :3].copy(), stats
+
+
+def sim_k2(data, seed=0, **kw):
+    """sim() with the chain walks taken from K2's per-position results (m4_k2.h), computed on the host."""
+    a, buf, out, p = _args(data, **kw)
+    L = lib()
+    L.sim_find_matches_k2.restype = ctypes.c_int64
+    L.sim_find_matches_k2.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_int] * 6 + \
+        [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]
+    r = L.sim_find_matches_k2(buf.ctypes.data, len(a), *p, seed, out.ctypes.data, len(out))
+    assert r >= 0, r
+    return out[:r, :3].copy()
+
+
+def k2_reference(data, **kw):
+    """K2's results for one fresh chunk by chain walks on the host: ((n, 4) uint32 results, (n,) uint8 marks)."""
+    a, buf, _, p = _args(data, **kw)
+    L = lib()
+    L.sim_k2_reference.restype = None
+    L.sim_k2_reference.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 2
+    res = np.zeros((len(a), 4), dtype=np.uint32)
+    mark = np.zeros(len(a), dtype=np.uint8)
+    L.sim_k2_reference(buf.ctypes.data, len(a), *p, res.ctypes.data, mark.ctypes.data)
+    return res, mark
