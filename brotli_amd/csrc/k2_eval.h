@@ -176,11 +176,20 @@ constexpr int K2E_ROWS = K2E_THREADS + K2E_HALO;
 constexpr int K2E_DW = (K2_BW + K2_FW) / 4; // 12 dwords per window
 constexpr int K2_MAX_CHAIN = K2E_HALO - 1;  // ChainLength K2 can serve
 
+
+constexpr int K2E_QUEUE = 4; // candidates a lane holds back before the whole wave runs k2_add
+
+// The inner loop is bound by instruction issue (every wave runs as many rounds as its deepest bucket has
+// entries, 65 at most), so a round does the least it can: one LDS word for the 4-byte test, the candidate's
+// window as three 16-byte LDS reads, k2_pair, and the champion test (k2_filter).  The 1.7 candidates per
+// position that pass it wait in a small per-lane queue; the full update of the kept list (k2_add, ~150
+// instructions) runs for the whole wave only when some lane's queue is full, and once at the end.
 __global__ __launch_bounds__(K2E_THREADS) void k2_eval(
     const uint8_t *__restrict__ src_base, uint64_t src_total, const uint32_t *__restrict__ sorted_base,
     uint32_t *__restrict__ chain_base, K2Res *__restrict__ res_base, const Job *__restrict__ jobs, int njobs,
     uint32_t wpj, ParseParams P) {
-  __shared__ uint32_t win[K2E_DW][K2E_ROWS]; // [dword][entry]: a wave's lanes read consecutive words
+  __shared__ uint4 win[K2E_ROWS][3];       // [entry]: the 48 bytes around its position
+  __shared__ uint32_t first4[K2E_ROWS];    // [entry]: the 4 bytes at its position (consecutive lanes, no conflicts)
   __shared__ uint32_t meta[K2E_ROWS];
   uint32_t job, part;
   if (!k2_job_of_block(blockIdx.x, wpj, njobs, job, part)) return;
@@ -203,9 +212,8 @@ __global__ __launch_bounds__(K2E_THREADS) void k2_eval(
       v2 = load_group(src_base, g + 32, (int64_t)src_total);
     }
     meta[e] = word;
-    win[0][e] = v0.x, win[1][e] = v0.y, win[2][e] = v0.z, win[3][e] = v0.w;
-    win[4][e] = v1.x, win[5][e] = v1.y, win[6][e] = v1.z, win[7][e] = v1.w;
-    win[8][e] = v2.x, win[9][e] = v2.y, win[10][e] = v2.z, win[11][e] = v2.w;
+    first4[e] = v1.x;
+    win[e][0] = v0, win[e][1] = v1, win[e][2] = v2;
   }
   __syncthreads();
   const int me = K2E_HALO + tid;
@@ -216,16 +224,33 @@ __global__ __launch_bounds__(K2E_THREADS) void k2_eval(
   uint32_t cw = 0;
   if (live) cw = *cw_ptr;
   uint32_t a[K2E_DW];
-#pragma unroll
-  for (int w = 0; w < K2E_DW; w++) a[w] = win[w][me];
+  {
+    const uint4 a0 = win[me][0], a1 = win[me][1], a2 = win[me][2];
+    a[0] = a0.x, a[1] = a0.y, a[2] = a0.z, a[3] = a0.w, a[4] = a1.x, a[5] = a1.y, a[6] = a1.z, a[7] = a1.w;
+    a[8] = a2.x, a[9] = a2.y, a[10] = a2.z, a[11] = a2.w;
+  }
   const int32_t avail_f = min(K2_FW, (int32_t)J.len - pos);
   // the walk: the table entry, then up to ChainLength hops (m4.go:159, 166)
   int32_t nwalk = live ? min((int32_t)(myword >> kSortDepthShift), P.chain_length + 1) : 0;
-  uint32_t kept[K2_ENTRIES];
+  uint32_t kept[K2_ENTRIES], q[K2E_QUEUE];
 #pragma unroll
   for (int k = 0; k < K2_ENTRIES; k++) kept[k] = 0;
-  int n = 0;
+#pragma unroll
+  for (int k = 0; k < K2E_QUEUE; k++) q[k] = 0;
+  int n = 0, qn = 0;
   bool fb = false;
+  int32_t ch0 = INT32_MIN, ch1 = INT32_MIN;
+  auto drain = [&]() {
+#pragma unroll
+    for (int t = 0; t < K2E_QUEUE; t++) {
+      if (!__any(t < qn)) break;
+      if (t < qn && !fb && !k2_add(kept, n, q[t], P.min_length, P.distance_bit_cost)) {
+        fb = true;
+        nwalk = 0;
+      }
+    }
+    qn = 0;
+  };
 #pragma unroll 1
   for (int32_t k = 1; __any(k <= nwalk); k++) {
     bool on = k <= nwalk;
@@ -237,20 +262,24 @@ __global__ __launch_bounds__(K2E_THREADS) void k2_eval(
       on = false;
       nwalk = 0;
     }
-    const bool hit = on && win[4][ce] == a[4];
+    const bool hit = on && first4[ce] == a[4];
     if (__any(hit)) {
-      uint32_t bw[K2E_DW];
+      const uint4 b0 = win[ce][0], b1 = win[ce][1], b2 = win[ce][2];
+      const uint32_t bw[K2E_DW] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+      uint32_t code = 0;
+      bool pass = hit && k2_pair(a, bw, avail_f, min(K2_BW, cpos), code);
+      const uint32_t e = (uint32_t)dist | code;
+      pass = pass && k2_filter(ch0, ch1, e, P.min_length, P.distance_bit_cost);
+      if (pass) {
 #pragma unroll
-      for (int w = 0; w < K2E_DW; w++) bw[w] = win[w][ce];
-      uint32_t code;
-      if (hit && k2_pair(a, bw, avail_f, min(K2_BW, cpos), code)) {
-        if (!k2_add(kept, n, (uint32_t)dist | code, P.min_length, P.distance_bit_cost)) {
-          fb = true;
-          nwalk = 0;
-        }
+        for (int t = 0; t < K2E_QUEUE; t++)
+          if (t == qn) q[t] = e;
+        qn++;
       }
+      if (__any(qn == K2E_QUEUE)) drain();
     }
   }
+  drain();
   if (!live) return;
   const bool mark = fb || n > 0;
   if (mark) {

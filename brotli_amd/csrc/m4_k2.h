@@ -116,6 +116,27 @@ M4G_HD bool k2_add(uint32_t *kept, int &n, uint32_t e, int32_t min_length, int32
   return true;
 }
 
+// A cheap test in front of k2_add, for the kernel's inner loop: most candidates lose, for every L, against ONE
+// earlier candidate -- the "champion", the best one at L = 0 so far.  ch0 / ch1 are the champion's scores at
+// L = 0 and at L = infinity (lower bounds if it is capped; INT32_MIN: no champion yet); a champion is longer
+// than MinLength at L = 0 already, so it is long enough whenever the candidate is.  Returns true when e has to
+// go through k2_add.  Dropping a candidate here rests on the EXISTENCE of a nearer candidate that is at least
+// as good for every L (ties go to the nearer one), whether or not that one is still kept: if it is beaten
+// later, then by a candidate that is better still.  The host reference applies the same test, so the results
+// are the same word for word.
+M4G_HD bool k2_filter(int32_t &ch0, int32_t &ch1, uint32_t e, int32_t min_length, int32_t cost) {
+  const int32_t f = k2_fwd(e), b = k2_bwd(e);
+  const bool capped = k2_capped(e);
+  const int32_t dterm = bitlen32(e & kK2DistMask) * cost;
+  const int32_t s0 = f * 256 - dterm, s1 = (f + b) * 256 - dterm;
+  const bool lost = !capped && ((s0 <= ch0 && s1 <= ch1) || f + b <= min_length || s1 <= 0);
+  if (f > min_length && s0 > ch0 && s1 >= ch1) {
+    ch0 = s0;
+    ch1 = s1;
+  }
+  return !lost;
+}
+
 // The selection of m4.go:156-181 over the kept candidates of position i.  Same flags, same comparisons as the
 // walk in parse_range; `len` may be shorter than the buffer K2 saw (speculative lanes), which the walk's own
 // extension would respect in the same way.

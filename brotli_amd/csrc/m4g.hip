@@ -192,6 +192,14 @@ void spec_use_worst(SpecWork &w) {
   w.st = w.rs + w.group_jobs * w.L.kmax * w.slot_worst;
 }
 
+// K2 serves fresh-state jobs built by the split K1, whose positions and distances fit the packed entries.
+bool k2_usable(const Params &p, size_t max_chunk_bytes) {
+  // Opt-in (M4G_K2=1, read at every plan creation): on text K2 evaluates 6 times the candidates the parse would
+  // visit and pays for a sort of the positions on top, which costs more than the parse saves.
+  const char *e = std::getenv("M4G_K2");
+  return e && std::atoi(e) != 0 && p.chain_length > 0 && p.chain_length <= K2_MAX_CHAIN && p.distance_bit_cost >= 0 &&
+         p.min_length >= 1 && max_chunk_bytes < (size_t)kK2MaxLen;
+}
 constexpr int kDefaultSubBlock = 1024;
 
 // Lanes a single streaming call is spread over at least (spec_alloc's min_lanes).
@@ -224,6 +232,13 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
   if (!min_lanes && !std::getenv("M4G_SUB_BLOCK") && p.chain_length == 0 && max_jobs * max_bytes >= ((size_t)1 << 30) &&
       max_bytes >= ((size_t)1 << 17)) // (chain walks are latency bound and want every lane they can get: params D 158 -> 184 ms per GiB)
     w.L.sub_block = 2 * kDefaultSubBlock;
+  // Chain walks: the parse is a string of dependent far reads per lane, and what shortens the stage is more lanes
+  // walking at once (measured, 256 x 1 MiB of text under ChainLength 64, tools/d_sub_ab.sh: sub-blocks of 1024 / 512 /
+  // 256 / 128 / 64 bytes: K3 40.8 / 35.3 / 30.9 / 28.5 / 30.7 ms, K4 0.16 / 0.22 / 0.37 / 0.69 / 1.28).  Plans that
+  // run K2 (k2_eval.h) walk (almost) no chains in the parse and keep the default.
+  if (!min_lanes && !std::getenv("M4G_SUB_BLOCK") && p.chain_length > 0 && !k2_usable(p, max_bytes) &&
+      max_jobs * max_bytes >= ((size_t)1 << 26) && max_bytes >= ((size_t)1 << 14))
+    w.L.sub_block = kDefaultSubBlock / 8;
   if (min_lanes && !std::getenv("M4G_SUB_BLOCK")) {
     int sub = 64;
     while (sub < w.L.sub_block && (size_t)sub * min_lanes < max_bytes) sub *= 2;
@@ -401,12 +416,6 @@ struct K2Work {
   K2Res *res = nullptr;       // one per chain entry; until k2_place has run its first quarter holds the depths
   size_t bytes = 0;
 };
-// K2 serves fresh-state jobs built by the split K1, whose positions and distances fit the packed entries.
-bool k2_usable(const Params &p, size_t max_chunk_bytes) {
-  static const bool off = std::getenv("M4G_NO_K2") != nullptr;
-  return !off && p.chain_length > 0 && p.chain_length <= K2_MAX_CHAIN && p.distance_bit_cost >= 0 &&
-         p.min_length >= 1 && max_chunk_bytes < (size_t)kK2MaxLen;
-}
 // K2 for the jobs in d_jobs, whose un-folded keys the split K1 has just left in split.keys / split.hdr.
 int launch_k2(const Params &p, const K2Work &k, const K1Split &split, const uint8_t *d_src, uint64_t src_total,
               uint32_t max_len, uint32_t *d_chain, const Job *d_jobs, int njobs, hipStream_t st) {
@@ -427,8 +436,10 @@ int launch_k2(const Params &p, const K2Work &k, const K1Split &split, const uint
                      k.sorted, d_jobs, njobs, wpj_p, p.hash_len, p.table_bits);
   HIP_TRY(hipGetLastError());
   const uint32_t wpj_e = (max_len + K2E_THREADS - 1) / K2E_THREADS;
+  ParseParams PP = parse_params(p);
+  if (const char *dbg = std::getenv("M4G_K2_DEBUG_WALK")) PP.chain_length = std::atoi(dbg) - 1; // timing aid: WRONG results
   hipLaunchKernelGGL(k2_eval, dim3((unsigned)groups * 8 * wpj_e), dim3(K2E_THREADS), 0, st, d_src, src_total, k.sorted,
-                     d_chain, k.res, d_jobs, njobs, wpj_e, parse_params(p));
+                     d_chain, k.res, d_jobs, njobs, wpj_e, PP);
   HIP_TRY(hipGetLastError());
   return M4G_OK;
 }

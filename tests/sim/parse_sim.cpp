@@ -432,6 +432,7 @@ void sim_k2_reference(const uint8_t *src, int32_t n, int max_distance, int min_l
     K2Res r{};
     int cnt = 0;
     bool fb = false;
+    int32_t ch0 = INT32_MIN, ch1 = INT32_MIN;
     if (i < n - 7) {
       uint32_t d = chain[i] & kChainDelta;
       int cand = i;
@@ -444,7 +445,8 @@ void sim_k2_reference(const uint8_t *src, int32_t n, int max_distance, int min_l
         uint32_t wc[12], code;
         window(cand, wc);
         const int af = n - i < K2_FW ? n - i : K2_FW, ab = cand < K2_BW ? cand : K2_BW;
-        if (k2_pair(wi, wc, af, ab, code) && !k2_add(r.e, cnt, (uint32_t)(i - cand) | code, min_length, distance_bit_cost))
+        if (k2_pair(wi, wc, af, ab, code) && k2_filter(ch0, ch1, (uint32_t)(i - cand) | code, min_length, distance_bit_cost) &&
+            !k2_add(r.e, cnt, (uint32_t)(i - cand) | code, min_length, distance_bit_cost))
           fb = true;
         d = chain[cand] & kChainDelta;
       }

@@ -13,6 +13,12 @@ from sim_lib import k2_reference
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _k2_on(monkeypatch):
+    """K2 is opt-in (M4G_K2=1, read when a plan is created): on text it costs more than it saves."""
+    monkeypatch.setenv("M4G_K2", "1")
+
 D = dict(MaxDistance=16777200, ChainLength=64, HashLen=5, DistanceBitCost=66)  # BASELINE config 4
 PARAMS = [
     D,
@@ -95,12 +101,32 @@ def test_k2_results_and_match_lists(pi):
         assert same(with_k2[c], again[c]), f"chunk {c}: second run with K2 differs"
 
 
-def test_plans_without_k2():
+def test_plans_without_k2(monkeypatch):
     assert m4.BatchPlan(4, 1 << 16, 0, MaxDistance=1 << 20, DistanceBitCost=66).info()["k2"] == 0, "ChainLength 0"
     assert m4.BatchPlan(2, 1 << 22, 0, **D).info()["k2"] == 0, "chunks of 4 MiB: distances do not fit the entries"
     p = m4.BatchPlan(2, (1 << 22) - 1, 0, **D)
     assert p.info()["k2"] == 1
     assert not m4.BatchPlan(2, 1 << 16, 0, MaxDistance=1 << 20).set_k2(True), "no buffers, nothing to switch"
+    monkeypatch.delenv("M4G_K2")
+    assert m4.BatchPlan(2, 1 << 16, 0, **D).info()["k2"] == 0, "not asked for"
+
+
+def test_chain_walking_plans_of_64_mib_and_more_parse_in_128_byte_sub_blocks(monkeypatch):
+    """Without K2 a large chain-walking plan spreads the walks over 8 times the lanes (m4g.hip, spec_alloc):
+    64 x 1 MiB of text under BASELINE config 4, eight chunks against the oracle, the rest through their sums."""
+    monkeypatch.delenv("M4G_K2")
+    n, C = 1 << 20, 64
+    host = np.empty(n * C, dtype=np.uint8)
+    synth.fill(host, n, 0, "text", 8)
+    chunks = [host[c * n:(c + 1) * n].tobytes() for c in range(C)]
+    plan = m4.BatchPlan(C, n, 0, **D)
+    info = plan.info()
+    assert info["k2"] == 0 and info["slot_worst"] == 128 // 4 + 18
+    got = _run(plan, chunks)
+    for c in list(range(0, C, 9)):
+        assert same(got[c], OracleM4(**D).FindMatches(chunks[c])), f"chunk {c}"
+    for c in range(C):
+        assert int(got[c][:, 0].sum() + got[c][:, 1].sum()) == n, f"chunk {c}: the list does not tile the chunk"
 
 
 def test_config4_one_mib_chunks_with_k2():

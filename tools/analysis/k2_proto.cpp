@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
   auto fill = (void (*)(void *, size_t, uint64_t, size_t, int, int))dlsym(h, "m4g_synth_fill");
   std::vector<uint8_t> buf((size_t)n * chunks + 64);
   fill(buf.data(), n, 0, chunks, kind, 4);
-  uint64_t hist[8] = {0}, marked = 0, capped = 0, bad = 0, recs = 0;
+  uint64_t passed = 0, hist[8] = {0}, marked = 0, capped = 0, bad = 0, recs = 0;
   for (int c = 0; c < chunks; c++) {
     const uint8_t *src = buf.data() + (size_t)c * n;
     std::vector<uint32_t> table(1 << 17, 0), chain(n + 8, 0);
@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
       K2Res r{};
       int cnt = 0;
       bool fb = false;
+      int32_t ch0 = INT32_MIN, ch1 = INT32_MIN;
       uint32_t d = chain[i] & kChainDelta;
       int cand = i;
       uint32_t wi[12];
@@ -79,7 +80,8 @@ int main(int argc, char **argv) {
         uint32_t wc[12], info;
         window(src, n, cand, wc);
         const int af = n - i < K2_FW ? n - i : K2_FW, ab = cand < K2_BW ? cand : K2_BW;
-        if (k2_pair(wi, wc, af, ab, info)) {
+        if (k2_pair(wi, wc, af, ab, info) && k2_filter(ch0, ch1, (uint32_t)(i - cand) | info, min_len, cost)) {
+          passed++;
           if (!k2_add(r.e, cnt, (uint32_t)(i - cand) | info, min_len, cost)) fb = true;
         }
         d = chain[cand] & kChainDelta;
@@ -117,5 +119,6 @@ int main(int argc, char **argv) {
          hist[0] / tot, hist[1] / tot, (hist[2]+hist[3]+hist[4]) / tot, hist[7] / tot, marked / tot, capped / tot);
   printf("chain hops per KiB (walks left in the parse) %.1f, k2 selections per KiB %.1f, iterations per KiB %.1f\n",
          g_cnt[24] / tot * 1024 / 3, g_cnt[30] / tot * 1024 / 2, g_cnt[0] / tot * 1024 / 3);
+  printf("candidates through the champion test into k2_add: %.3f per position\n", passed / tot);
   return bad != 0;
 }
