@@ -11,8 +11,11 @@
 //               a COUNTER here; a key's fetch-and-add is the number of earlier positions with its hash
 //               (depth), and the final counters are the bucket sizes.  Same ordering argument as k1c.
 //   k2_scan_sizes  exclusive prefix sum of a job's bucket sizes -> bucket bases.
-//   k2_place    sorted[base[hash(i)] + depth(i)] = i: the job's positions grouped by bucket, ascending.
-//               The walk of i is then sorted[r-1], sorted[r-2], ... with r = i's index: no pointer to chase.
+//   k2_place    sorted[base[hash(i)] + depth(i)] = i's entry (SortEnt, m4_parse.h: position, depth, the 4 bytes
+//               before and the 8 bytes at it): the job's positions grouped by bucket, ascending; rank[i] = that
+//               index.  The walk of i is then sorted[r-1], sorted[r-2], ... with r = rank[i]: no pointer to chase,
+//               and the parse (parse_range's sorted walk, the default for chain-walking batch plans) decides
+//               most candidates from the entries alone.
 //   k2_eval     one lane per sorted entry: 48 bytes around the position are fetched ONCE into LDS, and the
 //               lane compares its own with those of the up to ChainLength + 1 entries before it in its
 //               bucket (ds_read, no memory), keeping the candidates that can win for some state of the parse
@@ -23,9 +26,8 @@
 
 namespace m4g {
 
-constexpr uint32_t kSortPosMask = kK2DistMask;   // sorted word: position | min(depth, 127) << 22
-constexpr uint32_t kSortDepthShift = kK2DistBits;
-constexpr uint32_t kSortDepthCap = 127;
+static_assert(kSortPosBits == kK2DistBits, "positions and distances share their width");
+constexpr uint32_t kSortDepthShift = kSortPosBits;
 
 // One workgroup per (job, table partition), wave w owns 1/16 of the partition's counters and walks ITS bin of
 // every tile (k1c_scatter's structure: no barrier inside the loop).  Requires keys WITHOUT run folding
@@ -142,31 +144,48 @@ __device__ __forceinline__ bool k2_job_of_block(uint32_t b, uint32_t wpj, int nj
   return job < (uint32_t)njobs;
 }
 
+// sorted[base[hash(p)] + depth(p)] = the entry of p; rank[p] (in place of depth[p]) = that index | depth.
 __global__ __launch_bounds__(K2P_THREADS) void k2_place(
-    const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ depth_base, uint32_t depth_stride,
-    const uint32_t *__restrict__ base_base, uint32_t *__restrict__ sorted_base, const Job *__restrict__ jobs,
-    int njobs, uint32_t wpj, int hash_len, int table_bits) {
+    const uint8_t *__restrict__ src_base, uint32_t *__restrict__ rank_base, const uint32_t *__restrict__ base_base,
+    SortEnt *__restrict__ sorted_base, const Job *__restrict__ jobs, int njobs, uint32_t wpj, int hash_len,
+    int table_bits) {
   uint32_t job, part;
   if (!k2_job_of_block(blockIdx.x, wpj, njobs, job, part)) return;
   const Job J = jobs[job];
   const uint32_t end = J.len >= 8 ? J.len - 7 : 0; // positions < end are inserted (m4.go:112)
   const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
   const uint8_t *src = src_base + J.src_off;
-  const uint32_t *depth = depth_base + J.chain_off * (uint64_t)depth_stride;
+  uint32_t *rank = rank_base + J.chain_off;
   const uint32_t *base = base_base + ((uint64_t)job << table_bits);
-  uint32_t *sorted = sorted_base + J.chain_off;
+  SortEnt *sorted = sorted_base + J.chain_off;
 #pragma unroll 4
   for (int it = 0; it < K2P_PER; it++) {
     const uint32_t p = part * (K2P_THREADS * K2P_PER) + it * K2P_THREADS + threadIdx.x;
     if (p >= end) continue;
     uint64_t v;
     __builtin_memcpy(&v, src + p, 8); // p + 8 <= len
+    uint32_t before;
+    if (J.src_off + p >= 4) {
+      __builtin_memcpy(&before, src + p - 4, 4); // (p < 4: partly the previous chunk's bytes, which are never used)
+    } else { // the first bytes of the whole source buffer: bytes [0, p) of the job in the top lanes
+      uint32_t v0;
+      __builtin_memcpy(&v0, src, 4);
+      before = p ? v0 << (8 * (4 - p)) : 0u;
+    }
     const uint32_t h = (uint32_t)(((v & mask) * kHashMul64) >> (64 - table_bits));
-    const uint32_t d = depth[(uint64_t)p * depth_stride];
+    const uint32_t d = rank[p]; // depth, left by k1d_depth
     const uint32_t idx = base[h] + d;
+    const uint32_t dc = min(d, kSortDepthCap) << kSortDepthShift;
     // (idx < end by construction: every inserted position has a key, the bases sum the counts; the test keeps
     // a violated assumption from becoming a store outside the array)
-    if (idx < end) sorted[idx] = p | (min(d, kSortDepthCap) << kSortDepthShift);
+    if (idx < end) {
+      SortEnt e;
+      e.word = p | dc;
+      e.before4 = before;
+      e.at8 = v;
+      sorted[idx] = e;
+    }
+    rank[p] = (idx < end ? idx : 0u) | dc;
   }
 }
 
@@ -185,7 +204,7 @@ constexpr int K2E_QUEUE = 4; // candidates a lane holds back before the whole wa
 // position that pass it wait in a small per-lane queue; the full update of the kept list (k2_add, ~150
 // instructions) runs for the whole wave only when some lane's queue is full, and once at the end.
 __global__ __launch_bounds__(K2E_THREADS) void k2_eval(
-    const uint8_t *__restrict__ src_base, uint64_t src_total, const uint32_t *__restrict__ sorted_base,
+    const uint8_t *__restrict__ src_base, uint64_t src_total, const SortEnt *__restrict__ sorted_base,
     uint32_t *__restrict__ chain_base, K2Res *__restrict__ res_base, const Job *__restrict__ jobs, int njobs,
     uint32_t wpj, ParseParams P) {
   __shared__ uint4 win[K2E_ROWS][3];       // [entry]: the 48 bytes around its position
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(K2E_THREADS) void k2_eval(
   const int32_t end = J.len >= 8 ? (int32_t)J.len - 7 : 0;
   const int32_t s0 = (int32_t)part * K2E_THREADS;
   if (s0 >= end) return;
-  const uint32_t *sorted = sorted_base + J.chain_off;
+  const SortEnt *sorted = sorted_base + J.chain_off;
   const int tid = threadIdx.x;
   // ---- the windows of this workgroup's entries and of the K2E_HALO entries before them ----
   for (int e = tid; e < K2E_ROWS; e += K2E_THREADS) {
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(K2E_THREADS) void k2_eval(
     uint32_t word = 0;
     uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0;
     if (s >= 0 && s < end) {
-      word = sorted[s];
+      word = sorted[s].word;
       const int64_t g = (int64_t)J.src_off + (int64_t)(word & kSortPosMask) - K2_BW;
       v0 = load_group(src_base, g, (int64_t)src_total);
       v1 = load_group(src_base, g + 16, (int64_t)src_total);

@@ -573,6 +573,11 @@ struct StagedMem {
   const K2Res *k2;      // K2's results for this job's positions, or null (m4_k2.h)
   __device__ __forceinline__ bool has_k2() const { return k2 != nullptr; }
   __device__ __forceinline__ const K2Res *k2_ptr(int32_t p) const { return k2 + p; }
+  const SortEnt *sw;    // the job's sorted position list and the positions' indices in it, or null (m4_parse.h)
+  const uint32_t *rank;
+  __device__ __forceinline__ bool has_sw() const { return sw != nullptr; }
+  __device__ __forceinline__ const SortEnt *sw_ptr(int32_t r) const { return sw + r; }
+  __device__ __forceinline__ uint32_t rank_at(int32_t p) const { return rank[p]; }
   __device__ __forceinline__ uint8_t ld8(int32_t p) const {
     const uint32_t o = (uint32_t)(p - w0 + K3_BACK);
     if (o < (uint32_t)K3_SRC_BYTES) return (uint8_t)(lsrc[o >> 2] >> (8 * (o & 3)));
@@ -710,12 +715,12 @@ __device__ __forceinline__ uint64_t k3_wave_of_block(uint32_t b, uint32_t nblock
 #endif
 constexpr int32_t K3_EXT_LIMIT = M4G_K3_EXT_LIMIT;
 
-template <bool LIGHT>
+template <bool LIGHT, bool XW = false /* parse_range's switch of the same name */>
 __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
     const uint8_t *__restrict__ src_base, uint64_t src_total,
     const uint32_t *__restrict__ chain_base, const Job *__restrict__ jobs, Rec *__restrict__ rs,
     ParseState *__restrict__ E, BlockDesc *__restrict__ desc, uint32_t *__restrict__ errors,
-    int njobs, SpecLayout L, ParseParams P) {
+    int njobs, SpecLayout L, ParseParams P, int budget /* > 0: per-lane windows, see below */) {
   __shared__ uint32_t lds_src[K3_THREADS * K3_SRC_DW];
   __shared__ uint32_t lds_ch[K3_THREADS * K3_CH_DW];
   const int lane = threadIdx.x;
@@ -742,8 +747,36 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
   M.lch = lds_ch + lane * K3_CH_DW;
   M.give_up_at = len_eff < len ? len_eff : 0;
   M.k2 = P.k2 ? P.k2 + J.chain_off : nullptr;
+  M.sw = P.sw ? P.sw + J.chain_off : nullptr;
+  M.rank = P.rank ? P.rank + J.chain_off : nullptr;
   bool aborted = false;
 
+  if (budget > 0) {
+    // Chain walks: the work of 16 positions differs a lot from lane to lane (a lane whose positions all lie in
+    // crowded buckets walks 65 candidates at each, most lanes a few), and in lockstep epochs every lane waits for
+    // the slowest one of its wave, 64 times per sub-block.  Here every lane has its OWN window, staged where the
+    // lane stands (a lane that jumped over a match skips the windows in between), and a pass ends after `budget`
+    // rounds of the parse loop at the latest: lanes with light windows move on, a lane deep in walks continues
+    // in its next window from where it stopped.
+    int32_t at = bb;
+    while (__any(active && !aborted && at < be)) {
+      const bool row_on = active && !aborted && at < be;
+      const int32_t w0 = at & ~3; // (chain rows are copied in 16-byte pieces: keep them word-aligned as the epochs do)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      k3_stage(src_base, (int64_t)src_total, chain_base, lds_src, lds_ch, lane, row_on,
+               (int64_t)J.src_off + w0, (int64_t)J.chain_off + w0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (row_on) {
+        M.w0 = w0;
+        parse_range<false, LIGHT, true, true, XW>(M, len_eff, P, S, min(w0 + K3_W, be), sink, budget);
+        aborted = len_eff < len && (S.error & kStateTouchedEnd);
+        at = S.i;
+      }
+    }
+  } else
   for (int32_t e = 0; e < L.sub_block; e += K3_W) { // uniform trip count
     const int32_t w0 = bb + e;
     const bool row_on = active && !aborted && w0 < be;
@@ -759,7 +792,7 @@ __global__ __launch_bounds__(K3_THREADS, M4G_K3_MINWAVES) void k3a_spec(
       // (the LIGHT filter pays only without chain walks: with ChainLength > 0 every entry within MaxDistance is an
       // event, and params D measured 158 ms per GiB with it against 144 without)
       // (two instantiations, chosen at the launch: both in one kernel cost it its fourth wave per SIMD)
-      parse_range<false, LIGHT>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
+      parse_range<false, LIGHT, true, true, XW>(M, len_eff, P, S, min(w0 + K3_W, be), sink);
       aborted = len_eff < len && (S.error & kStateTouchedEnd);
     }
   }
@@ -1128,7 +1161,7 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
 #ifndef M4G_K3B_MINWAVES
 #define M4G_K3B_MINWAVES 6
 #endif
-template <bool CHAIN>
+template <bool CHAIN, bool XW = false>
 __global__ __launch_bounds__(K3_THREADS, CHAIN ? 4 : M4G_K3B_MINWAVES) void k3b_stitch(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, const Rec *__restrict__ rs, Rec *__restrict__ st,
@@ -1176,8 +1209,9 @@ __global__ __launch_bounds__(K3_THREADS, CHAIN ? 4 : M4G_K3B_MINWAVES) void k3b_
       return;
     }
   }
-  GlobalMem M{src, chain, CHAIN && P.k2 ? P.k2 + J.chain_off : nullptr};
-  if (stitch_chase<CHAIN>(M, (int32_t)J.len, P, g, k, rs + t * L.slot, L.slot, E + t, desc + t, K3_EXT_LIMIT, T, sink, d))
+  GlobalMem M{src, chain, CHAIN && P.k2 ? P.k2 + J.chain_off : nullptr, CHAIN && P.sw ? P.sw + J.chain_off : nullptr,
+              CHAIN && P.rank ? P.rank + J.chain_off : nullptr};
+  if (stitch_chase<CHAIN, XW>(M, (int32_t)J.len, P, g, k, rs + t * L.slot, L.slot, E + t, desc + t, K3_EXT_LIMIT, T, sink, d))
     Tout[t] = T;
   desc[t] = d;
   if (sink.n > L.slot) atomicOr(errors, 2u);
@@ -1293,6 +1327,7 @@ __device__ __forceinline__ void k3c_stage(WaveMem &M, uint32_t *lsrc, uint32_t *
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool XW = false>
 __global__ __launch_bounds__(64) void k3c_validate(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, Rec *__restrict__ rs, Rec *__restrict__ st,
@@ -1484,6 +1519,8 @@ __global__ __launch_bounds__(64) void k3c_validate(
       M.src = src;
       M.chain = chain;
       M.k2 = P.k2 ? P.k2 + J.chain_off : nullptr;
+      M.sw = P.sw ? P.sw + J.chain_off : nullptr;
+      M.rank = P.rank ? P.rank + J.chain_off : nullptr;
       k3c_stage(M, c_src, c_ch, len, bb, be, lane);
       // the block's speculative records, which the stitch scans for a common flush, staged the same way
       const Rec *spec = rs + t * L.slot;
@@ -1494,7 +1531,7 @@ __global__ __launch_bounds__(64) void k3c_validate(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         spec = c_rec;
       }
-      const bool ok = stitch_block(M, len, P, g, (int32_t)k, spec, n_spec, Ek, T, sink, keep);
+      const bool ok = stitch_block<true, XW>(M, len, P, g, (int32_t)k, spec, n_spec, Ek, T, sink, keep);
       if (sink.n > L.slot) err |= 2u;
       if (lane == 0) {
         BlockDesc nd = d;

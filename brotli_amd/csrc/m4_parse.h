@@ -35,6 +35,7 @@
 namespace m4g {
 
 struct K2Res;
+struct SortEnt;
 struct ParseParams {
   int32_t max_distance;
   int32_t min_length;
@@ -44,6 +45,10 @@ struct ParseParams {
   // results of kernel K2 for the chain array the parse reads (element j of it speaks about chain[j]), or null:
   // set by the host for plans that run K2 (m4_k2.h); the kernels hand job J's part to their memory accessor
   const K2Res *k2 = nullptr;
+  // the bucket-sorted position list and every position's index in it (k2_eval.h: k2_place), or null: with them
+  // the walk of m4.go:166-181 reads its candidates from consecutive list entries instead of chasing the chain
+  const SortEnt *sw = nullptr;
+  const uint32_t *rank = nullptr;
 };
 
 // emitter.go:5-16; end == 0 <=> the reference's zero-valued absoluteMatch
@@ -107,10 +112,28 @@ struct K2Res {
   uint32_t e[K2_ENTRIES];
 };
 static_assert(sizeof(K2Res) == 16, "one 16-byte word per position");
+// One entry of a job's bucket-sorted position list (k2_eval.h): the positions with one table index stand next
+// to each other, ascending, so the candidates of the walk from the entry at index r are the entries r-1, r-2, ...
+// An entry carries the 4 bytes before and the 8 bytes at its position: most candidates are decided from those
+// (m4.go:175-176: the 4-byte test, and every match shorter than 8 forward / 4 backward) without touching the
+// candidate's own cache line.
+constexpr uint32_t kSortPosBits = 22, kSortPosMask = (1u << kSortPosBits) - 1; // word: position | min(depth, 127) << 22
+constexpr uint32_t kSortDepthCap = 127;                                         // depth = earlier positions in the bucket
+struct SortEnt {
+  uint32_t word;    // position | min(depth, kSortDepthCap) << kSortPosBits
+  uint32_t before4; // bytes [p-4, p) (little endian; what lies before the buffer is arbitrary)
+  uint64_t at8;     // bytes [p, p+8)
+};
+static_assert(sizeof(SortEnt) == 16, "one 16-byte word per position");
 struct GlobalMem {
   const uint8_t *src;
   const uint32_t *chain;
   const K2Res *k2 = nullptr; // per-position results of K2 (m4_k2.h), or none
+  const SortEnt *sw = nullptr; // the job's sorted position list, or none
+  const uint32_t *rank = nullptr; // per position: index in sw | min(depth, 127) << 22
+  M4G_HD bool has_sw() const { return sw != nullptr; }
+  M4G_HD const SortEnt *sw_ptr(int32_t r) const { return sw + r; }
+  M4G_HD uint32_t rank_at(int32_t p) const { return rank[p]; }
   M4G_HD uint8_t ld8(int32_t p) const { return src[p]; }
   M4G_HD uint32_t ld32(int32_t p) const { return m4g::ld32(src + p); }
   M4G_HD uint64_t ld64(int32_t p) const { return m4g::ld64(src + p); }
@@ -344,17 +367,98 @@ namespace m4g {
 // (m4.go:235-253) out -- for callers that know ChainLength == 0; FUSED = false reads a candidate's
 // bytes where they are used (match_at) instead of all together at the top of the iteration: less
 // code and fewer registers for callers that run a single, rare iteration (k3a_fast's parked lanes).
-template <bool STOP_AT_FLUSH = false, bool LIGHT = false, bool CHAIN = true, bool FUSED = true, class Mem, class Sink>
+// XW = true (with CHAIN) compiles in the two other sources of a walk's candidates: K2's per-position results
+// (m4_k2.h; Mem::has_k2()) and the bucket-sorted position list (SortEnt; Mem::has_sw()), chosen at run time by
+// what the accessor carries.  The kernels of the default path are instantiated without them: the extra state
+// cost k3a_spec 20 % under ChainLength 64 (160 spilled registers) even when unused.
+template <bool STOP_AT_FLUSH = false, bool LIGHT = false, bool CHAIN = true, bool FUSED = true, bool XW = false, class Mem, class Sink>
 M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseState &S,
-                        int32_t stop, Sink &sink) {
+                        int32_t stop, Sink &sink, int32_t budget = 0x7FFFFFFF /* rounds of the loop, at most (a walk
+                        in progress is finished first); the caller goes on from S.i */) {
   int32_t i = S.i;
   bool k2_on = false; // the walks of m4.go:156-181 come from K2 (m4_k2.h)
-  if constexpr (CHAIN) k2_on = P.chain_length > 0 && M.has_k2();
+  if constexpr (CHAIN && XW) k2_on = P.chain_length > 0 && M.has_k2();
+  bool sw_on = false; // the hops of m4.go:166-181 read the sorted position list (SortEnt)
+  if constexpr (CHAIN && XW) sw_on = P.chain_length > 0 && !k2_on && M.has_sw();
   // 8 source bytes of the repeat probe, kept across iterations: consecutive
   // literal positions probe consecutive addresses (same prev_dist).
   uint64_t pc_bytes = 0;
   int32_t pc_base = -0x40000000;
+  // The walk over the sorted list is SUSPENDED between batches of four candidates: a lane inside a walk takes one
+  // batch per round of this loop while the other lanes of its wave go on with their positions.  (Run to the end
+  // where it starts, every position of every lane costs the wave the longest walk among its 64 lanes -- measured:
+  // 4 % of the lanes active in the hop loop, and no gain over chasing the chain.)
+  bool walking = false;
+  int32_t w_next = 0, w_left = 0; // the next entry to read (they are read downwards), candidates left
+  AbsMatch cur{0, 0, 0};
   while (i < stop) {
+   if (!(CHAIN && XW && walking) && budget <= 0) break;
+   budget--;
+   if (CHAIN && XW && walking) {
+    if constexpr (CHAIN && XW) {
+      int64_t cur_score = score(cur, P.distance_bit_cost); // (0 for the empty match, as at the start of the walk)
+      AbsMatch m;
+      const uint64_t my8 = M.ld64(i);
+      const uint32_t myb = i >= 4 ? M.ld32(i - 4) : (M.ld32(0) << (8 * (4 - i))); // (i >= 1: position 0 has no candidate)
+      // Four entries per round trip; an entry decides its candidate unless the match reaches 8 bytes forward or 4
+      // (usable) bytes backward -- then the candidate's bytes are read as before (match_at).  Same candidates in the
+      // same order as the chain gives, same comparisons.
+      SortEnt ent[4];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (int t = 0; t < 4; t++) ent[t] = *M.sw_ptr(w_next - (t < w_left ? t : 0));
+      const int32_t nb4 = w_left < 4 ? w_left : 4;
+      w_next -= 4;
+      w_left -= nb4;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (int t = 0; t < 4; t++) {
+        if (t >= nb4) break;
+        M4G_STAT(24);
+        const int32_t c2 = (int32_t)(ent[t].word & kSortPosMask);
+        if (c2 <= 0 || i - c2 > P.max_distance) { // position 0 reads as "none"; beyond MaxDistance the walk ends
+          w_left = 0;
+          break;
+        }
+        const uint64_t x = ent[t].at8 ^ my8;
+        if ((uint32_t)x != 0) continue; // m4.go:175
+        bool hop_hit = true;
+        const int32_t maxb = (i - S.next_emit) < c2 ? (i - S.next_emit) : c2;
+        int32_t nb = 0;
+        bool real = x == 0;
+        if (!real && maxb > 0) {
+          const uint32_t y = ent[t].before4 ^ myb;
+          nb = y != 0 ? (int32_t)(__builtin_clz(y) >> 3) : 4;
+          if (nb > maxb) nb = maxb;
+          else if (nb == 4 && maxb > 4) real = true;
+        }
+        if (real) {
+          M4G_STAT(31);
+          hop_hit = match_at(M, len, i, c2, S.next_emit, m);
+        } else {
+          m.end = i + (int32_t)(__builtin_ctzll(x) >> 3);
+          m.start = i - nb;
+          m.match = c2 - nb;
+        }
+        if (hop_hit) {
+          M4G_STAT(25);
+          if (!S.have_prev && m.start == S.next_emit) S.error |= kStateHitLo;
+          if (m.end >= len) S.error |= kStateTouchedEnd;
+          if (m.end - m.start > P.min_length) {
+            const int64_t sc = score(m, P.distance_bit_cost);
+            if (sc > cur_score) {
+              cur = m;
+              cur_score = sc;
+            }
+          }
+        }
+      }
+      if (w_left > 0) continue;
+      walking = false; // ... and on to m4.go:183 with `cur`
+    }
+   } else {
     if (LIGHT) {
       bool event = false;
       do {
@@ -365,7 +469,7 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
         const uint32_t le = M.near_chain(i);
         // (with K2's results the mark of an entry says "some candidate of the walk can be accepted")
         if ((le & kChainDelta) - 1u < (uint32_t)P.max_distance &&
-            ((le & kChainMaybe) || (P.chain_length > 0 && !(CHAIN && k2_on)))) {
+            ((le & kChainMaybe) || (P.chain_length > 0 && !(CHAIN && XW && k2_on)))) {
           event = true; // a candidate to look at
           break;
         }
@@ -417,8 +521,12 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
       cb = M.far64(cand_fast ? cand - 8 : 0);
       cf2 = M.far64(cand_fast2 ? cand + 8 : 0);
     }
+    uint32_t rk = 0;
+    if constexpr (CHAIN && XW) {
+      if (sw_on && cand_ok) rk = M.rank_at(i); // (with the other far words of the iteration)
+    }
     K2Res k2r{};
-    if constexpr (CHAIN) {
+    if constexpr (CHAIN && XW) {
       // (read with the other far words of the iteration; positions without an accepted candidate have no mark)
       if (k2_on && cand_ok && (ce & kChainMaybe)) __builtin_memcpy(&k2r, M.k2_ptr(i), sizeof(K2Res));
     }
@@ -465,11 +573,11 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     }
 
     // E. m4.go:156-181
-    AbsMatch cur{0, 0, 0};
+    cur = AbsMatch{0, 0, 0};
     int64_t cur_score = 0;
     AbsMatch m;
     bool walk = true;
-    if constexpr (CHAIN) {
+    if constexpr (CHAIN && XW) {
       if (k2_on) {
         walk = (ce & kChainMaybe) && k2r.e[0] == kK2Fallback;
         if ((ce & kChainMaybe) && !walk) {
@@ -498,6 +606,20 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
     }
     // m4.go:166-181.  The chain entry of a candidate and the bytes around it are
     // read together (one far round trip per hop instead of two dependent ones).
+    if constexpr (CHAIN && XW) {
+      if (sw_on) {
+        // The hops come from the sorted list, in later rounds of this loop (see its top): candidate j of the walk
+        // (0 = the table entry, handled above) is the entry j + 1 below this position's own.
+        walk = false;
+        const int32_t depth = (int32_t)(rk >> kSortPosBits);
+        w_left = (depth < P.chain_length + 1 ? depth : P.chain_length + 1) - 1;
+        w_next = (int32_t)(rk & kSortPosMask) - 2;
+        if (w_left > 0) {
+          walking = true;
+          continue;
+        }
+      }
+    }
     uint32_t next_entry = CHAIN && walk && P.chain_length > 0 ? M.chain_at(cand) : 0u;
     for (int32_t j = 0; CHAIN && walk && j < P.chain_length; j++) {
       uint32_t dd = next_entry & kChainDelta;
@@ -530,6 +652,8 @@ M4G_HD bool parse_range(const Mem &M, int32_t len, const ParseParams &P, ParseSt
         }
       }
     }
+   } // (!walking)
+    const int64_t cur_score = score(cur, P.distance_bit_cost); // (= the walk's running score; 0 for the empty match)
     // m4.go:183-185
     if (cur.end - cur.start < P.min_length) {
       M4G_STAT(12);

@@ -81,7 +81,7 @@ M4G_HD void spec_parse_block(const Mem &M, int32_t len, const ParseParams &P,
 // updated to the true state entering block k+1.  Returns true when the block
 // synchronised with its speculative parse.
 // CHAIN = false: for callers that know ChainLength == 0 (parse_range's switch of the same name).
-template <bool CHAIN = true, class Mem, class Sink>
+template <bool CHAIN = true, bool XW = false, class Mem, class Sink>
 M4G_HD bool stitch_block(const Mem &M, int32_t len, const ParseParams &P,
                          const SpecGeom &g, int32_t k, const Rec *__restrict__ spec,
                          uint32_t n_spec, const ParseState &E, ParseState &T, Sink &sink,
@@ -90,7 +90,7 @@ M4G_HD bool stitch_block(const Mem &M, int32_t len, const ParseParams &P,
   uint32_t j = 0;
   bool synced = false;
   while (T.i < stop) {
-    if (!parse_range<true, false, CHAIN>(M, len, P, T, stop, sink)) break;
+    if (!parse_range<true, false, CHAIN, true, XW>(M, len, P, T, stop, sink)) break;
     // a flush just happened: the last record ends at T.next_emit (== T.i)
     const int32_t e = T.next_emit;
     while (j < n_spec && rec_end(spec[j]) < e) j++;
@@ -140,7 +140,7 @@ constexpr uint32_t K3_MAX_CHASE = 63;
 // E_k / desc_k / rs_k point at block k's entries of the per-job arrays (block
 // k + x is entry x; slot records per block).  Fills d (status word in out_off);
 // returns true when T must be kept as Tout[k] (the block did not synchronise).
-template <bool CHAIN = true, class Mem, class Sink>
+template <bool CHAIN = true, bool XW = false, class Mem, class Sink>
 M4G_HD bool stitch_chase(const Mem &M, int32_t len, const ParseParams &P, const SpecGeom &g,
                          uint32_t k, const Rec *rs_k, uint32_t slot, const ParseState *E_k,
                          const BlockDesc *desc_k, int32_t ext_limit, ParseState &T, Sink &sink,
@@ -154,7 +154,7 @@ M4G_HD bool stitch_chase(const Mem &M, int32_t len, const ParseParams &P, const 
     const ParseState &Eb = E_k[extra];
     uint32_t n_spec = 0;
     if (!(Eb.error & kStateAborted)) n_spec = desc_k[extra].n_spec < slot ? desc_k[extra].n_spec : slot;
-    ok = stitch_block<CHAIN>(M, len_eff, P, g, (int32_t)b, rs_k + (size_t)extra * slot, n_spec, Eb, T, sink, keep);
+    ok = stitch_block<CHAIN, XW>(M, len_eff, P, g, (int32_t)b, rs_k + (size_t)extra * slot, n_spec, Eb, T, sink, keep);
     gave_up = len_eff < len && (T.error & kStateTouchedEnd);
     // A pending match that reaches past the block end leaves nothing to compare
     // with yet: go on into the next block (no records so far, so the slot

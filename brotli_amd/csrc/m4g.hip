@@ -200,6 +200,15 @@ bool k2_usable(const Params &p, size_t max_chunk_bytes) {
   return e && std::atoi(e) != 0 && p.chain_length > 0 && p.chain_length <= K2_MAX_CHAIN && p.distance_bit_cost >= 0 &&
          p.min_length >= 1 && max_chunk_bytes < (size_t)kK2MaxLen;
 }
+// The sorted position list serves fresh-state jobs built by the split K1 whose positions fit its entries.
+bool sw_usable(const Params &p, size_t max_chunk_bytes) {
+  // Opt-in (M4G_SW=1, read at every plan creation; K2 needs it and switches it on): the list costs a sort of the
+  // positions (k1d_depth + k2_place: 10 ms per 256 MiB) and the parse that reads it is no faster than the one that
+  // chases the chain (DESIGN.md 3.2c has the measurements and what they say about the bound).
+  const char *e = std::getenv("M4G_SW"), *e2 = std::getenv("M4G_K2");
+  return ((e && std::atoi(e) != 0) || (e2 && std::atoi(e2) != 0)) && p.chain_length > 0 && p.chain_length + 1 <= (int)kSortDepthCap &&
+         max_chunk_bytes < ((size_t)1 << kSortPosBits);
+}
 constexpr int kDefaultSubBlock = 1024;
 
 // Lanes a single streaming call is spread over at least (spec_alloc's min_lanes).
@@ -236,7 +245,7 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
   // walking at once (measured, 256 x 1 MiB of text under ChainLength 64, tools/d_sub_ab.sh: sub-blocks of 1024 / 512 /
   // 256 / 128 / 64 bytes: K3 40.8 / 35.3 / 30.9 / 28.5 / 30.7 ms, K4 0.16 / 0.22 / 0.37 / 0.69 / 1.28).  Plans that
   // run K2 (k2_eval.h) walk (almost) no chains in the parse and keep the default.
-  if (!min_lanes && !std::getenv("M4G_SUB_BLOCK") && p.chain_length > 0 && !k2_usable(p, max_bytes) &&
+  if (!min_lanes && !std::getenv("M4G_SUB_BLOCK") && p.chain_length > 0 && !(k2_usable(p, max_bytes) && sw_usable(p, max_bytes)) &&
       max_jobs * max_bytes >= ((size_t)1 << 26) && max_bytes >= ((size_t)1 << 14))
     w.L.sub_block = kDefaultSubBlock / 8;
   if (min_lanes && !std::getenv("M4G_SUB_BLOCK")) {
@@ -294,6 +303,16 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
   return M4G_OK;
 }
 
+// Device buffers of the sorted position list (k2_eval.h) for a batch plan, and of K2 when that is asked for.
+struct K2Work {
+  bool sw = false;            // the plan builds the list and its parse walks it (the default for ChainLength > 0)
+  bool on = false;            // ... and K2 evaluates every position's walk ahead of the parse (M4G_K2=1)
+  SortEnt *sorted = nullptr;  // the positions of every job grouped by table index (indexed like the chain array)
+  uint32_t *base = nullptr;   // njobs << table_bits: bucket sizes, then bucket bases
+  uint32_t *rank = nullptr;   // per chain entry: depth in its bucket (k1d_depth), then index in `sorted` | depth
+  K2Res *res = nullptr;       // K2 only: one per chain entry
+  size_t bytes = 0;
+};
 // Buffers of the split K1 (k1_split.h): the bin-sorted keys of every tile and the
 // per-tile bin headers.  keys == nullptr: the caller has none (streaming handle,
 // the entry point that allocates nothing) and K1 is the one-kernel form.
@@ -374,9 +393,14 @@ int launch_k1(const Params &p, const uint8_t *d_src, uint64_t src_total, uint32_
 // in w.rs / w.st as described by w.desc.
 int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, const uint32_t *d_chain,
                  const Job *d_jobs, int njobs, const SpecWork &w, uint32_t *d_counts, uint32_t *d_errors,
-                 hipStream_t st, const K2Res *k2 = nullptr /* K2's results for d_chain's positions (launch_k2) */) {
+                 hipStream_t st, const K2Work *kw = nullptr /* what launch_k2 has built for d_chain's positions */) {
   ParseParams P = parse_params(p);
+  const K2Res *k2 = kw && kw->on ? kw->res : nullptr;
   P.k2 = k2;
+  if (kw && kw->sw && !k2) {
+    P.sw = kw->sorted;
+    P.rank = kw->rank;
+  }
   const uint64_t lanes = (uint64_t)njobs * w.L.kmax;
   const unsigned g3 = (unsigned)((lanes + K3_THREADS - 1) / K3_THREADS);
   // tuning aid: unused dynamic LDS per workgroup = fewer waves per CU = fewer chunks in flight per XCD
@@ -386,37 +410,48 @@ int launch_parse(const Params &p, const uint8_t *d_src, uint64_t src_total, cons
   if (P.chain_length == 0 && w.L.kmax % K3_THREADS == 0 && !k3a_slow)
     hipLaunchKernelGGL(k3a_fast, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
                        w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
-  else if (P.chain_length == 0 || k2) // (with K2's results only marked entries are events, as without chains)
-    hipLaunchKernelGGL(k3a_spec<true>, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
-                       w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
-  else
-    hipLaunchKernelGGL(k3a_spec<false>, dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain, d_jobs,
-                       w.rs, w.E, w.desc, d_errors, njobs, w.L, P);
+  else if (P.chain_length == 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k3a_spec<true, false>), dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain,
+                       d_jobs, w.rs, w.E, w.desc, d_errors, njobs, w.L, P, 0);
+  else if (k2) // (with K2's results only marked entries are events, as without chains)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k3a_spec<true, true>), dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total, d_chain,
+                       d_jobs, w.rs, w.E, w.desc, d_errors, njobs, w.L, P, 0);
+  else {
+    // chain walks inside the parse: per-lane windows with a round budget (kernels.h, k3a_spec)
+    static const int budget = std::getenv("M4G_K3_BUDGET") ? std::atoi(std::getenv("M4G_K3_BUDGET")) : 24;
+    if (P.sw)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k3a_spec<false, true>), dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total,
+                         d_chain, d_jobs, w.rs, w.E, w.desc, d_errors, njobs, w.L, P, budget);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k3a_spec<false, false>), dim3(g3), dim3(K3_THREADS), k3a_pad, st, d_src, src_total,
+                         d_chain, d_jobs, w.rs, w.E, w.desc, d_errors, njobs, w.L, P, budget);
+  }
   HIP_TRY(hipGetLastError());
+  const bool xw = k2 || P.sw; // the kernels that read K2's results / the sorted list (parse_range's XW)
   if (w.L.kmax > 1) {
     if (P.chain_length == 0)
-      hipLaunchKernelGGL(k3b_stitch<false>, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k3b_stitch<false, false>), dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
+                         w.st, w.E, w.Tout, w.desc, d_errors, njobs, w.L, P);
+    else if (xw)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k3b_stitch<true, true>), dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
                          w.st, w.E, w.Tout, w.desc, d_errors, njobs, w.L, P);
     else
-      hipLaunchKernelGGL(k3b_stitch<true>, dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k3b_stitch<true, false>), dim3(g3), dim3(K3_THREADS), 0, st, d_src, d_chain, d_jobs, w.rs,
                          w.st, w.E, w.Tout, w.desc, d_errors, njobs, w.L, P);
     HIP_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(k3c_validate, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain, d_jobs,
-                     w.rs, w.st, w.E, w.Tout, w.desc, d_counts, d_errors, njobs, w.L, P);
+  if (xw)
+    hipLaunchKernelGGL(k3c_validate<true>, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain, d_jobs,
+                       w.rs, w.st, w.E, w.Tout, w.desc, d_counts, d_errors, njobs, w.L, P);
+  else
+    hipLaunchKernelGGL(k3c_validate<false>, dim3((unsigned)njobs), dim3(64), 0, st, d_src, d_chain, d_jobs,
+                       w.rs, w.st, w.E, w.Tout, w.desc, d_counts, d_errors, njobs, w.L, P);
   HIP_TRY(hipGetLastError());
   return M4G_OK;
 }
 
-// Device buffers of K2 (k2_eval.h) for a batch plan.
-struct K2Work {
-  bool on = false;
-  uint32_t *sorted = nullptr; // the positions of every job grouped by table index (indexed like the chain array)
-  uint32_t *base = nullptr;   // njobs << table_bits: bucket sizes, then bucket bases
-  K2Res *res = nullptr;       // one per chain entry; until k2_place has run its first quarter holds the depths
-  size_t bytes = 0;
-};
-// K2 for the jobs in d_jobs, whose un-folded keys the split K1 has just left in split.keys / split.hdr.
+// The sorted position list (and K2, when the plan runs it) for the jobs in d_jobs, whose un-folded keys the split
+// K1 has just left in split.keys / split.hdr.
 int launch_k2(const Params &p, const K2Work &k, const K1Split &split, const uint8_t *d_src, uint64_t src_total,
               uint32_t max_len, uint32_t *d_chain, const Job *d_jobs, int njobs, hipStream_t st) {
   const int pb = part_bits_of(p);
@@ -425,16 +460,16 @@ int launch_k2(const Params &p, const K2Work &k, const K1Split &split, const uint
   int posbits = 1;
   while (posbits < 32 && (max_len >> posbits) != 0) posbits++;
   const int cb = std::max(0, std::min(K1_MAX_CHECK_BITS, 32 - posbits)); // as launch_k1
-  uint32_t *depth = reinterpret_cast<uint32_t *>(k.res);
   hipLaunchKernelGGL(k1d_depth, dim3((unsigned)(groups * 8 * nparts)), dim3(KP_THREADS), k1s_lds_bytes(pb), st, split.keys,
-                     split.hdr, depth, 1u, k.base, d_jobs, njobs, split.kt_max, p.table_bits, pb, cb);
+                     split.hdr, k.rank, 1u, k.base, d_jobs, njobs, split.kt_max, p.table_bits, pb, cb);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k2_scan_sizes, dim3((unsigned)njobs), dim3(1024), 0, st, k.base, njobs, p.table_bits);
   HIP_TRY(hipGetLastError());
   const uint32_t wpj_p = (max_len + K2P_THREADS * K2P_PER - 1) / (K2P_THREADS * K2P_PER);
-  hipLaunchKernelGGL(k2_place, dim3((unsigned)groups * 8 * wpj_p), dim3(K2P_THREADS), 0, st, d_src, depth, 1u, k.base,
+  hipLaunchKernelGGL(k2_place, dim3((unsigned)groups * 8 * wpj_p), dim3(K2P_THREADS), 0, st, d_src, k.rank, k.base,
                      k.sorted, d_jobs, njobs, wpj_p, p.hash_len, p.table_bits);
   HIP_TRY(hipGetLastError());
+  if (!k.on) return M4G_OK;
   const uint32_t wpj_e = (max_len + K2E_THREADS - 1) / K2E_THREADS;
   ParseParams PP = parse_params(p);
   if (const char *dbg = std::getenv("M4G_K2_DEBUG_WALK")) PP.chain_length = std::atoi(dbg) - 1; // timing aid: WRONG results
@@ -633,6 +668,7 @@ extern "C" void m4g_batch_destroy(m4g_batch *b) {
   (void)hipFree(b->W.k2.sorted);
   (void)hipFree(b->W.k2.base);
   (void)hipFree(b->W.k2.res);
+  (void)hipFree(b->W.k2.rank);
   if (b->W.side) (void)hipStreamSynchronize(b->W.side), (void)hipStreamDestroy(b->W.side);
   for (hipEvent_t e : {b->W.ev_fork, b->W.ev_scan, b->W.ev_join})
     if (e) (void)hipEventDestroy(e);
@@ -720,19 +756,22 @@ int batch_create(const m4g_params *params, int device, size_t max_chunks, size_t
     }
     b->bytes += hdr_bytes;
   }
-  if (split && b->W.split.keys && k2_usable(p, max_chunk_bytes)) {
+  if (split && b->W.split.keys && sw_usable(p, max_chunk_bytes)) {
     K2Work &k = b->W.k2;
     const size_t entries = chain_bytes / 4 + 1024;
     const size_t base_bytes = (max_chunks << p.table_bits) * 4;
-    if (hipMalloc(&k.sorted, entries * 4) != hipSuccess || hipMalloc(&k.base, base_bytes) != hipSuccess ||
-        hipMalloc(&k.res, entries * sizeof(K2Res)) != hipSuccess) {
-      // (not an error: the plan runs without K2, walking the chains inside the parse)
+    const bool want_k2 = k2_usable(p, max_chunk_bytes);
+    if (hipMalloc(&k.sorted, entries * sizeof(SortEnt)) != hipSuccess || hipMalloc(&k.base, base_bytes) != hipSuccess ||
+        hipMalloc(&k.rank, entries * 4) != hipSuccess ||
+        (want_k2 && hipMalloc(&k.res, entries * sizeof(K2Res)) != hipSuccess)) {
+      // (not an error: the plan runs without the list, chasing the chains inside the parse)
       (void)hipGetLastError();
-      (void)hipFree(k.sorted), (void)hipFree(k.base), (void)hipFree(k.res);
+      (void)hipFree(k.sorted), (void)hipFree(k.base), (void)hipFree(k.rank), (void)hipFree(k.res);
       k = K2Work{};
     } else {
-      k.on = true;
-      k.bytes = entries * (4 + sizeof(K2Res)) + base_bytes;
+      k.sw = true;
+      k.on = want_k2;
+      k.bytes = entries * (sizeof(SortEnt) + 4 + (want_k2 ? sizeof(K2Res) : 0)) + base_bytes;
       b->bytes += k.bytes;
     }
   }
@@ -809,7 +848,7 @@ int run_batch_overlapped(const Params &p, const BatchWork &W, uint32_t max_len, 
   // (tools/overlap_ab.sh, text in 1 MiB chunks, overlapped against one stream: 256 chunks 5.10 / 5.10 ms, 512: 8.66 /
   // 8.86, 1024: 15.96 / 16.01, 2048: 30.93 / 31.32, 4096: 60.8 / 61.9)
   static const int min_jobs = std::getenv("M4G_OVERLAP_MIN_CHUNKS") ? std::atoi(std::getenv("M4G_OVERLAP_MIN_CHUNKS")) : 512;
-  if (off || W.k2.on || !W.side || !W.h_jobs || !w.arena || w.group_jobs || njobs < min_jobs || src_total < (uint64_t)min_jobs << 20 ||
+  if (off || W.k2.sw || !W.side || !W.h_jobs || !w.arena || w.group_jobs || njobs < min_jobs || src_total < (uint64_t)min_jobs << 20 ||
       W.split.keys != reinterpret_cast<uint32_t *>(w.rs))
     return 1;
   const int jm = njobs / 2, nb = njobs - jm;
@@ -898,12 +937,12 @@ int run_batch_pipeline(const Params &p, const BatchWork &W, uint32_t max_len, co
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
   bool split_ran = false;
   int rc = launch_k1(p, d_src, src_total, max_len, W.d_chain, W.d_jobs, nullptr, njobs, st, nullptr, nullptr, &W.split,
-                     !W.k2.on, &split_ran);
+                     !W.k2.sw, &split_ran);
   if (rc) return rc;
-  const K2Res *k2 = nullptr;
-  if (W.k2.on && split_ran) { // (stage K1 of the timing events includes K2)
+  const K2Work *k2 = nullptr;
+  if (W.k2.sw && split_ran) { // (stage K1 of the timing events includes the sort, and K2 when it runs)
     if ((rc = launch_k2(p, W.k2, W.split, d_src, src_total, max_len, W.d_chain, W.d_jobs, njobs, st))) return rc;
-    k2 = W.k2.res;
+    k2 = &W.k2;
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   uint32_t *n_long = W.d_errors + 8; // zeroed with d_errors above
@@ -1053,9 +1092,9 @@ extern "C" int m4g_batch_status(m4g_batch *b) {
 
 extern "C" int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap) {
   if (!b || !out) return 0;
-  const uint64_t v[7] = {b->bytes, b->W.w.L.slot, b->W.w.slot_worst, b->W.w.group_jobs, b->reruns,
-                         b->W.k2.on ? 1u : 0u, b->W.k2.bytes};
-  const int n = std::min(cap, 7);
+  const uint64_t v[8] = {b->bytes, b->W.w.L.slot, b->W.w.slot_worst, b->W.w.group_jobs, b->reruns,
+                         b->W.k2.on ? 1u : 0u, b->W.k2.bytes, b->W.k2.sw ? 1u : 0u};
+  const int n = std::min(cap, 8);
   for (int k = 0; k < n; k++) out[k] = v[k];
   return n;
 }
@@ -1066,6 +1105,13 @@ extern "C" int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap) {
 extern "C" int m4g_debug_batch_set_k2(m4g_batch *b, int on) {
   if (!b || !b->W.k2.res) return 0;
   b->W.k2.on = on != 0;
+  return 1;
+}
+// The same switch for the sorted position list (the parse chases the chains when it is off).
+extern "C" int m4g_debug_batch_set_sorted_walk(m4g_batch *b, int on) {
+  if (!b || !b->W.k2.sorted) return 0;
+  b->W.k2.sw = on != 0;
+  if (!on) b->W.k2.on = false;
   return 1;
 }
 extern "C" int m4g_debug_batch_dump_k2(m4g_batch *b, size_t c, uint32_t *chain_out, uint32_t *res_out, size_t n) {

@@ -44,7 +44,7 @@ EXPORTS = [
     "m4g_batch_create", "m4g_batch_destroy", "m4g_batch_run_device", "m4g_batch_run_device_codes",
     "m4g_find_matches_batch",
     "m4g_batch_last_timings", "m4g_batch_set_timing", "m4g_host_alloc", "m4g_host_free",
-    "m4g_batch_status", "m4g_batch_info", "m4g_debug_batch_set_k2", "m4g_debug_batch_dump_k2", "m4g_batch_run_device_noalloc", "m4g_debug_noalloc_poison", "m4g_find_matches_blocks_multi", "m4g_debug_span_plan", "m4g_bargain_ctx_create", "m4g_bargain_ctx_destroy", "m4g_bargain_ctx_reset", "m4g_bargain_ctx_find_blocks", "m4g_bargain_find_blocks_multi",
+    "m4g_batch_status", "m4g_batch_info", "m4g_debug_batch_set_k2", "m4g_debug_batch_set_sorted_walk", "m4g_debug_batch_dump_k2", "m4g_batch_run_device_noalloc", "m4g_debug_noalloc_poison", "m4g_find_matches_blocks_multi", "m4g_debug_span_plan", "m4g_bargain_ctx_create", "m4g_bargain_ctx_destroy", "m4g_bargain_ctx_reset", "m4g_bargain_ctx_find_blocks", "m4g_bargain_find_blocks_multi",
     "m4g_batch_encode", "m4g_batch_flate_encode", "m4g_flate_encode_blocks", "m4g_brotli_encode_blocks",
     "m4g_hostbatch_compress", "m4g_writer_create", "m4g_writer_write", "m4g_writer_close", "m4g_writer_reset", "m4g_writer_destroy", "m4g_hostbatch_create", "m4g_hostbatch_run", "m4g_hostbatch_destroy",
     "m4g_bargain_create", "m4g_bargain_destroy", "m4g_bargain_block_count", "m4g_bargain_run_device",
@@ -109,6 +109,7 @@ def lib():
         L.m4g_batch_status.argtypes = [vp]
         L.m4g_batch_info.argtypes = [vp, vp, ctypes.c_int]
         L.m4g_debug_batch_set_k2.argtypes = [vp, ctypes.c_int]
+        L.m4g_debug_batch_set_sorted_walk.argtypes = [vp, ctypes.c_int]
         L.m4g_debug_batch_dump_k2.argtypes = [vp, sz, vp, vp, sz]
         L.m4g_hostbatch_create.argtypes = [ctypes.POINTER(Params), vp, ctypes.c_int, sz, sz, ctypes.POINTER(vp)]
         L.m4g_hostbatch_run.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp]
@@ -409,14 +410,18 @@ class BatchPlan:
 
     def info(self) -> dict:
         """Device memory and record-slot layout of the plan (m4g_batch_info)."""
-        v = (ctypes.c_uint64 * 7)()
-        n = lib().m4g_batch_info(self._h, v, 7)
-        keys = ("bytes", "slot", "slot_worst", "group_chunks", "reruns", "k2", "k2_bytes")
+        v = (ctypes.c_uint64 * 8)()
+        n = lib().m4g_batch_info(self._h, v, 8)
+        keys = ("bytes", "slot", "slot_worst", "group_chunks", "reruns", "k2", "k2_bytes", "sorted_walk")
         return {k: int(v[i]) for i, k in enumerate(keys[:n])}
 
     def set_k2(self, on: bool) -> bool:
         """Test hook: run with / without K2 (the chain walks as a kernel of their own); False when the plan has none."""
         return bool(lib().m4g_debug_batch_set_k2(self._h, 1 if on else 0))
+
+    def set_sorted_walk(self, on: bool) -> bool:
+        """Test hook: the parse reads its walks from the sorted position list (True) or chases the chains."""
+        return bool(lib().m4g_debug_batch_set_sorted_walk(self._h, 1 if on else 0))
 
     def dump_k2(self, c: int, n: int):
         """Test hook: (chain entries, K2 results as an (n, 4) uint32 array) of chunk c of the last run."""

@@ -454,7 +454,9 @@ int m4g_batch_status(m4g_batch *b);
  * runs repeated so far (0 or 1).  Returns the number of values written.
  * out[5] = 1 when the plan evaluates the chain walks in a kernel of their own
  * (K2; ChainLength > 0, chunks below 4 MiB, DistanceBitCost >= 0), out[6] =
- * the device memory that takes (included in out[0]). */
+ * the device memory K2 and the sorted position list take (included in out[0]),
+ * out[7] = 1 when the plan builds that list and its parse reads the candidates
+ * of a walk from it (ChainLength > 0, chunks below 4 MiB; k2_eval.h). */
 int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap);
 /* Test hooks for K2, the data-parallel form of the chain walks of m4.go:156-181
  * (no counterpart in the reference: results are the same with and without).
@@ -463,6 +465,9 @@ int m4g_batch_info(m4g_batch *b, uint64_t *out, int cap);
  * a run, chunk c's chain entries and per-position K2 results (4 words each),
  * n <= the chunk's length of each, to host memory (either may be NULL). */
 int m4g_debug_batch_set_k2(m4g_batch *b, int on);
+/* The same switch for the sorted position list a chain-walking plan builds
+ * (out[7] of m4g_batch_info; the parse chases the chains when it is off). */
+int m4g_debug_batch_set_sorted_walk(m4g_batch *b, int on);
 int m4g_debug_batch_dump_k2(m4g_batch *b, size_t c, uint32_t *chain_out, uint32_t *res_out, size_t n);
 
 /* Per-stage kernel time of the plan's most recent run, measured with HIP

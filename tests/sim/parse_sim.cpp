@@ -476,7 +476,51 @@ int64_t sim_find_matches_k2(const uint8_t *src, int32_t n, int max_distance, int
   ParseState S;
   state_init(S, 0, seed_prev);
   GlobalMem M{src, chain.data(), res.data()};
-  parse_range<false, true>(M, n, P, S, n - 7, sink);
+  parse_range<false, true, true, true, true>(M, n, P, S, n - 7, sink);
+  parse_finish(n, P, S, sink);
+  if ((int64_t)sink.v.size() > out_cap) return -(int64_t)sink.v.size();
+  for (auto &r : sink.v) r.lit_start &= ~kRecFlushBit;
+  if (!sink.v.empty()) std::memcpy(out, sink.v.data(), sink.v.size() * sizeof(Rec));
+  return (S.error & m4g::kStateErrRange) ? INT64_MIN : (int64_t)sink.v.size();
+}
+// One fresh-state FindMatches whose parse reads the candidates of its walks from the bucket-sorted position list
+// (SortEnt, m4_parse.h), built here the way k1d_depth / k2_scan_sizes / k2_place build it.
+int64_t sim_find_matches_sw(const uint8_t *src, int32_t n, int max_distance, int min_length, int hash_len,
+                            int table_bits, int chain_length, int distance_bit_cost, uint32_t seed_prev,
+                            uint32_t *out, int64_t out_cap) {
+  ParseParams P{max_distance, min_length, hash_len, chain_length, distance_bit_cost};
+  std::vector<uint32_t> table((size_t)1 << table_bits, 0), chain((size_t)n + 8, 0);
+  build_chain(src, 0, n, hash_len, table_bits, table, chain.data());
+  const int32_t end = n >= 8 ? n - 7 : 0;
+  const uint64_t mask = hash_len >= 8 ? ~0ull : ((1ull << (8 * hash_len)) - 1);
+  std::vector<uint32_t> size((size_t)1 << table_bits, 0), rank((size_t)n + 1, 0), hs((size_t)n + 1, 0);
+  for (int32_t i = 0; i < end; i++) {
+    hs[i] = (uint32_t)(((ld64(src + i) & mask) * 0x1E35A7BD1E35A7BDull) >> (64 - table_bits));
+    rank[i] = size[hs[i]]++; // depth
+  }
+  uint32_t run = 0;
+  for (auto &v : size) {
+    const uint32_t c = v;
+    v = run;
+    run += c;
+  }
+  std::vector<SortEnt> sorted((size_t)n + 1);
+  for (int32_t i = 0; i < end; i++) {
+    const uint32_t d = rank[i], idx = size[hs[i]] + d, dc = (d < kSortDepthCap ? d : kSortDepthCap) << kSortPosBits;
+    SortEnt e;
+    e.word = (uint32_t)i | dc;
+    uint8_t b[4];
+    for (int k = 0; k < 4; k++) b[k] = i - 4 + k >= 0 ? src[i - 4 + k] : (uint8_t)(0x5A + k); // arbitrary before the buffer
+    std::memcpy(&e.before4, b, 4);
+    e.at8 = ld64(src + i);
+    sorted[idx] = e;
+    rank[i] = idx | dc;
+  }
+  VecSink sink;
+  ParseState S;
+  state_init(S, 0, seed_prev);
+  GlobalMem M{src, chain.data(), nullptr, sorted.data(), rank.data()};
+  parse_range<false, false, true, true, true>(M, n, P, S, n - 7, sink);
   parse_finish(n, P, S, sink);
   if ((int64_t)sink.v.size() > out_cap) return -(int64_t)sink.v.size();
   for (auto &r : sink.v) r.lit_start &= ~kRecFlushBit;

@@ -86,3 +86,15 @@ def k2_reference(data, **kw):
     mark = np.zeros(len(a), dtype=np.uint8)
     L.sim_k2_reference(buf.ctypes.data, len(a), *p, res.ctypes.data, mark.ctypes.data)
     return res, mark
+
+
+def sim_sw(data, seed=0, **kw):
+    """sim() with the walks' candidates read from the bucket-sorted position list (SortEnt), built on the host."""
+    a, buf, out, p = _args(data, **kw)
+    L = lib()
+    L.sim_find_matches_sw.restype = ctypes.c_int64
+    L.sim_find_matches_sw.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_int] * 6 + \
+        [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int64]
+    r = L.sim_find_matches_sw(buf.ctypes.data, len(a), *p, seed, out.ctypes.data, len(out))
+    assert r >= 0, r
+    return out[:r, :3].copy()

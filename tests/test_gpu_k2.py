@@ -108,12 +108,14 @@ def test_plans_without_k2(monkeypatch):
     assert p.info()["k2"] == 1
     assert not m4.BatchPlan(2, 1 << 16, 0, MaxDistance=1 << 20).set_k2(True), "no buffers, nothing to switch"
     monkeypatch.delenv("M4G_K2")
-    assert m4.BatchPlan(2, 1 << 16, 0, **D).info()["k2"] == 0, "not asked for"
+    info = m4.BatchPlan(2, 1 << 16, 0, **D).info()
+    assert info["k2"] == 0 and info["sorted_walk"] == 0, "not asked for"
 
 
-def test_chain_walking_plans_of_64_mib_and_more_parse_in_128_byte_sub_blocks(monkeypatch):
-    """Without K2 a large chain-walking plan spreads the walks over 8 times the lanes (m4g.hip, spec_alloc):
-    64 x 1 MiB of text under BASELINE config 4, eight chunks against the oracle, the rest through their sums."""
+def test_config4_64_chunks_of_one_mib_default_plan(monkeypatch):
+    """BASELINE config 4 through the default plan (the parse chases the chains; 128-byte sub-blocks, which
+    spec_alloc picks for chain-walking plans of 64 MiB and more): 64 x 1 MiB of text, eight chunks against the
+    oracle, the rest through their sums."""
     monkeypatch.delenv("M4G_K2")
     n, C = 1 << 20, 64
     host = np.empty(n * C, dtype=np.uint8)
@@ -121,7 +123,7 @@ def test_chain_walking_plans_of_64_mib_and_more_parse_in_128_byte_sub_blocks(mon
     chunks = [host[c * n:(c + 1) * n].tobytes() for c in range(C)]
     plan = m4.BatchPlan(C, n, 0, **D)
     info = plan.info()
-    assert info["k2"] == 0 and info["slot_worst"] == 128 // 4 + 18
+    assert info["k2"] == 0 and info["sorted_walk"] == 0 and info["slot_worst"] == 128 // 4 + 18
     got = _run(plan, chunks)
     for c in list(range(0, C, 9)):
         assert same(got[c], OracleM4(**D).FindMatches(chunks[c])), f"chunk {c}"
@@ -140,3 +142,25 @@ def test_config4_one_mib_chunks_with_k2():
     got = _run(plan, chunks)
     for c in range(C):
         assert same(got[c], OracleM4(**D).FindMatches(chunks[c])), f"chunk {c}"
+
+
+@pytest.mark.parametrize("pi", range(len(PARAMS) + 1))
+def test_sorted_walk_equals_the_chain_chase_and_the_oracle(pi, monkeypatch):
+    """M4G_SW=1: the parse reads a walk's candidates from the bucket-sorted position list (k2_place's SortEnt),
+    four per round of its loop, instead of chasing the chain.  Same Match lists as the oracle and as the same plan
+    with the list switched off."""
+    monkeypatch.delenv("M4G_K2")
+    monkeypatch.setenv("M4G_SW", "1")
+    kw = (PARAMS + [dict(MaxDistance=1 << 16, ChainLength=126, HashLen=4, TableBits=8)])[pi]
+    chunks = _chunks(seed=5 + pi)
+    plan = m4.BatchPlan(len(chunks), 1 << 16, 0, **kw)
+    info = plan.info()
+    assert info["sorted_walk"] == 1 and info["k2"] == 0
+    got = _run(plan, chunks)
+    for c, data in enumerate(chunks):
+        assert same(got[c], OracleM4(**kw).FindMatches(data)), f"chunk {c} differs from the oracle"
+    assert plan.set_sorted_walk(False)
+    chase = _run(plan, chunks)
+    assert plan.info()["sorted_walk"] == 0
+    for c in range(len(chunks)):
+        assert same(got[c], chase[c]), f"chunk {c}: sorted walk and chain chase differ"

@@ -8,8 +8,13 @@ import pytest
 from brotli_amd import synth
 from cases import edge_inputs, opticks
 from oracle_lib import OracleM4
-from sim_lib import k2_reference, sim, sim_k2
+from sim_lib import k2_reference, sim, sim_k2, sim_sw
 
+# (the sorted walk also serves DistanceBitCost < 0 and ChainLength up to 126, which K2 does not)
+PARAMS_SW_ONLY = [
+    dict(MaxDistance=1 << 16, ChainLength=126, HashLen=4, TableBits=8),
+    dict(MaxDistance=1 << 20, ChainLength=5, HashLen=5, DistanceBitCost=-40),
+]
 PARAMS = [
     dict(MaxDistance=16777200, ChainLength=64, HashLen=5, DistanceBitCost=66),   # BASELINE config 4
     dict(MaxDistance=1 << 20, MinLength=4, HashLen=5, TableBits=17, ChainLength=8),
@@ -51,6 +56,7 @@ def test_parse_with_k2_results_equals_the_chain_walking_parse(pi):
         ref = OracleM4(**kw).FindMatches(data)
         assert same(sim(data, **kw), ref), f"{name}: host parse differs from the oracle"
         assert same(sim_k2(data, **kw), ref), f"{name}: parse with K2 results differs from the oracle"
+        assert same(sim_sw(data, **kw), ref), f"{name}: parse over the sorted position list differs from the oracle"
 
 
 def test_edge_inputs_with_k2_results():
@@ -59,6 +65,7 @@ def test_edge_inputs_with_k2_results():
         if len(data) < 8:  # (the host harness reads 8 bytes per hash; shorter buffers have no loop position)
             continue
         assert same(sim_k2(data, **kw), OracleM4(**kw).FindMatches(data)), name
+        assert same(sim_sw(data, **kw), OracleM4(**kw).FindMatches(data)), name
 
 
 def test_results_keep_few_candidates_on_text_and_fall_back_on_long_repeats():
@@ -72,3 +79,10 @@ def test_results_keep_few_candidates_on_text_and_fall_back_on_long_repeats():
     assert ((res[two, 0] & 0x3FFFFF) < (res[two, 1] & 0x3FFFFF)).all()
     res, _ = k2_reference(inp["zeros"], **PARAMS[0])
     assert (res[100:40000, 0] == 0xFFFFFFFF).all(), "a zero page: every candidate agrees beyond the compared bytes"
+
+
+@pytest.mark.parametrize("pi", range(len(PARAMS_SW_ONLY)))
+def test_sorted_walk_parameter_sets_k2_does_not_serve(pi):
+    kw = PARAMS_SW_ONLY[pi]
+    for name, data in _inputs().items():
+        assert same(sim_sw(data, **kw), OracleM4(**kw).FindMatches(data)), name

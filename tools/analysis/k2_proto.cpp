@@ -101,8 +101,8 @@ int main(int argc, char **argv) {
       VecSink b;
       ParseState S; state_init(S, 0, 0);
       GlobalMem M{src, chain2.data(), k2.data()};
-      if (light) parse_range<false, true>(M, n, P, S, n - 7, b);
-      else parse_range(M, n, P, S, n - 7, b);
+      if (light) parse_range<false, true, true, true, true>(M, n, P, S, n - 7, b);
+      else parse_range<false, false, true, true, true>(M, n, P, S, n - 7, b);
       parse_finish(n, P, S, b);
       if (a.v.size() != b.v.size() || memcmp(a.v.data(), b.v.data(), a.v.size() * sizeof(Rec))) {
         bad++;
