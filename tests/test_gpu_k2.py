@@ -164,3 +164,27 @@ def test_sorted_walk_equals_the_chain_chase_and_the_oracle(pi, monkeypatch):
     assert plan.info()["sorted_walk"] == 0
     for c in range(len(chunks)):
         assert same(got[c], chase[c]), f"chunk {c}: sorted walk and chain chase differ"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_the_three_forms_of_the_walk(seed, monkeypatch):
+    """Random parameter sets with ChainLength > 0 x random structured inputs (tests/test_gpu_fuzz.py's generators):
+    the plan with K2, the plan with the sorted walk and the plan that chases the chain, each against the oracle."""
+    from test_gpu_fuzz import random_input, random_params
+    rng = np.random.default_rng(7000 + seed)
+    kw = random_params(rng)
+    kw["ChainLength"] = int(rng.choice([1, 3, 16, 64, 79]))
+    kw["TableBits"] = int(rng.choice([0, 6, 10, 14, 16, 17]))  # (tables above 2^17 have no split K1, hence no list)
+    sizes = [int(rng.choice([0, 1, 7, 8, 9, 63, 64, 3071, 3072, 3073, 4097])) for _ in range(3)] + \
+            [int(rng.integers(10, 60000)) for _ in range(6)]
+    chunks = [random_input(rng, s) for s in sizes]
+    ref = [OracleM4(**kw).FindMatches(c) for c in chunks]
+    for env in (dict(M4G_K2="1"), dict(M4G_K2="0", M4G_SW="1"), dict(M4G_K2="0", M4G_SW="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = m4.BatchPlan(len(chunks), 1 << 16, 0, **kw)
+        info = plan.info()
+        assert info["k2"] == int(env.get("M4G_K2") == "1") and info["sorted_walk"] == int("1" in env.values()), (env, info)
+        got = _run(plan, chunks)
+        for c in range(len(chunks)):
+            assert same(got[c], ref[c]), f"seed {seed} {kw} {env}: chunk {c} (len {sizes[c]}) differs from the oracle"
