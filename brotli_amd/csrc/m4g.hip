@@ -247,11 +247,14 @@ int spec_alloc(SpecWork &w, const Params &p, size_t max_jobs, size_t max_bytes, 
   // run K2 (k2_eval.h) walk (almost) no chains in the parse and keep the default.
   if (!min_lanes && !std::getenv("M4G_SUB_BLOCK") && p.chain_length > 0 && !(k2_usable(p, max_bytes) && sw_usable(p, max_bytes)) &&
       max_jobs * max_bytes >= ((size_t)1 << 26) && max_bytes >= ((size_t)1 << 14))
-    // (by chain length, tools/chain_sub_probe.py, K3 + K4 per 128 MiB at 1024 / 512 / 256 / 128 bytes: ChainLength 1: text
-    // 4.8 / 3.8 / 3.5 / 3.5 ms, log records 2.5 / 1.8 / 1.9 / 2.5; 8 (HashLen 4, 32 KiB window, the flate levels): 9.9 /
-    // 6.1 / 6.1 / 6.6 and 4.5 / 3.1 / 3.1 / 4.2; 32: 14.4 / 8.8 / 8.7 / 9.2 and 10.2 / 6.9 / 6.6 / 8.9 -- 256 bytes suit
-    // them all; only the longest chains gain from 128)
-    w.L.sub_block = p.chain_length >= 48 ? kDefaultSubBlock / 8 : kDefaultSubBlock / 4;
+    // (by chain length and window, tools/chain_sub_probe.py, K3 + K4 per 256 MiB at 1024 / 512 / 256 / 128 bytes --
+    // windows of 1 MiB: ChainLength 1: text 7.9 / 6.8 / 6.5 / 6.4 ms, log records 3.3 / 3.3 / 3.3 / 4.3; ChainLength 8: 17.9 /
+    // 14.9 / 13.6 / 12.4 and 7.0 / 6.5 / 6.1 / 7.7; windows of 32 KiB (the flate levels): ChainLength 16: 10.4 / 10.4 / 10.8 /
+    // 11.2 and 8.0 / 7.8 / 7.6 / 9.9, ChainLength 64: 12.2 / 12.0 / 12.4 / 12.7 and 17.6 / 17.1 / 17.0 / 21.3: far walks
+    // want lanes, near ones do not care, and 128 bytes pay only for the longest chains over the widest windows)
+    w.L.sub_block = p.max_distance <= (1 << 16) ? kDefaultSubBlock / 2
+                    : p.chain_length >= 48      ? kDefaultSubBlock / 8
+                                                : kDefaultSubBlock / 4;
   if (min_lanes && !std::getenv("M4G_SUB_BLOCK")) {
     int sub = 64;
     while (sub < w.L.sub_block && (size_t)sub * min_lanes < max_bytes) sub *= 2;
