@@ -9,7 +9,7 @@ lg = np.empty(C * n, dtype=np.uint8); synth.fill(lg, n, 0, "log", 16)
 dev = torch.device("cuda:0")
 off = np.arange(C + 1, dtype=np.uint64) * n
 d_out = torch.empty(3 * (n // 3 + 2) * C, dtype=torch.int32, device=dev); d_off = torch.empty(C + 1, dtype=torch.int64, device=dev)
-for chain, hl, md in ((1, 6, 1 << 20), (8, 5, 1 << 20), (8, 4, 32768), (32, 4, 32768), (2, 5, 32768), (16, 5, 32768), (64, 5, 32768)):
+for chain, hl, md in ((1, 6, 1 << 20), (8, 5, 1 << 20), (8, 4, 32768), (32, 4, 32768), (2, 5, 32768), (16, 5, 32768), (64, 5, 32768), (64, 5, 16777200)):
     kw = dict(MaxDistance=md, HashLen=hl, ChainLength=chain, DistanceBitCost=66)
     for name, host in (("text", t), ("log", lg)):
         d_src = torch.empty(C * n + 64, dtype=torch.uint8, device=dev); d_src[:C * n].copy_(torch.from_numpy(host))
