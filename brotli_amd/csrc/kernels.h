@@ -1161,8 +1161,11 @@ __global__ __launch_bounds__(K3_THREADS, M4G_KF_MINWAVES) void k3a_fast(
 #ifndef M4G_K3B_MINWAVES
 #define M4G_K3B_MINWAVES 6
 #endif
+#ifndef M4G_K3B_CHAIN_WAVES
+#define M4G_K3B_CHAIN_WAVES 6 // (ChainLength 64, 128-byte sub-blocks: 4 / 5 / 6 / 8 waves per SIMD 5.31 / 4.90 / 4.71 / 5.62 ms per 256 MiB)
+#endif
 template <bool CHAIN, bool XW = false>
-__global__ __launch_bounds__(K3_THREADS, CHAIN ? 4 : M4G_K3B_MINWAVES) void k3b_stitch(
+__global__ __launch_bounds__(K3_THREADS, CHAIN ? M4G_K3B_CHAIN_WAVES : M4G_K3B_MINWAVES) void k3b_stitch(
     const uint8_t *__restrict__ src_base, const uint32_t *__restrict__ chain_base,
     const Job *__restrict__ jobs, const Rec *__restrict__ rs, Rec *__restrict__ st,
     const ParseState *__restrict__ E, ParseState *__restrict__ Tout,
