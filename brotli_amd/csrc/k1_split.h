@@ -43,7 +43,7 @@ constexpr int KP_TILE = KP_THREADS * KP_ROWS;       // 3072 positions: ~48 keys 
 constexpr int KP_BINS = 64;                         // <= 4 partitions x 16 owner waves
 constexpr int KP_CSTRIDE = KP_BINS + 1;             // odd stride: a wave's counters spread over the banks
 #ifndef M4G_KP_TPW
-#define M4G_KP_TPW 4
+#define M4G_KP_TPW 8 // (1024 x 1 MiB of text, k1p per launch: 2 / 4 / 8 / 16 / 32 tiles: 2.64 / 2.64 / 2.55 / 2.57 / 2.53 ms)
 #endif
 constexpr int KP_TPW = M4G_KP_TPW;                         // tiles per k1p workgroup (consecutive, one job)
 constexpr int KP_KEY_IDX_SHIFT = 17;                // key = index in the owner's slice << 17 | rel << cb | check bits
